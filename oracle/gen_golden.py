@@ -1,0 +1,341 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.json by running the REAL reference (pangenome/impop)
+functions on seeded inputs.  Runs only in the build container, where
+/root/reference exists; the GPU box only ever sees the JSON it writes.
+
+The reference is imported by file path; nothing from it
+is copied: the fixtures hold inputs (bit matrices, identity tables, argument
+values) and the reference's full-precision outputs (float.hex()).
+
+Usage: python3 oracle/gen_golden.py [--ref /root/reference] [--out tests/golden]
+"""
+from __future__ import annotations
+
+import argparse
+import base64
+import importlib.util
+import io
+import json
+import os
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+sys.dont_write_bytecode = True
+
+
+def load(name, path):
+    spec = importlib.util.spec_from_file_location(name, path)
+    m = importlib.util.module_from_spec(spec)
+    sys.modules[name] = m  # tj_d.py's @dataclass needs the module registered
+    spec.loader.exec_module(m)
+    return m
+
+
+def hx(x):
+    return None if x is None else float(x).hex()
+
+
+def names_for(n, ctg="chr1", s0=0, s1=1000):
+    # PanSN-like, already in lexicographic order: sample#hap#contig:start-end
+    out = []
+    for i in range(n):
+        out.append(f"S{(i // 2):04d}#{(i % 2) + 1}#{ctg}:{s0}-{s1}")
+    assert out == sorted(out)
+    return out
+
+
+def b64(a: np.ndarray) -> str:
+    return base64.b64encode(np.ascontiguousarray(a).tobytes()).decode()
+
+
+def pack_rows(m01):
+    n, W = m01.shape
+    words = (W + 63) // 64
+    pad = np.zeros((n, words * 64), dtype=np.uint8)
+    pad[:, :W] = m01
+    return np.packbits(pad, axis=1, bitorder="little").view(np.uint64).reshape(n, words)
+
+
+def np_counts(m01):
+    m = m01.astype(np.int64)
+    return m @ m.T  # I_ij
+
+
+def np_identity(I, W, kind):
+    a = np.diag(I)
+    n = I.shape[0]
+    sim = np.zeros((n, n))
+    for i in range(n):
+        for j in range(n):
+            if kind == "match":
+                H = int(a[i] + a[j] - 2 * I[i, j])
+                sim[i, j] = (W - H) / W
+            else:
+                d = int(a[i] + a[j])
+                sim[i, j] = (2 * int(I[i, j])) / d if d else 1.0
+    return sim
+
+
+def sim_dict(sim, names):
+    d = {}
+    n = len(names)
+    for i in range(n):
+        for j in range(i, n):
+            d[(names[i], names[j])] = float(sim[i, j])
+    return d
+
+
+def is_equivalence(sim, thr, rd):
+    n = sim.shape[0]
+    s = sim if rd is None else np.vectorize(lambda v: round(float(v), rd))(sim)
+    adj = s > thr
+    np.fill_diagonal(adj, True)
+    # transitive <=> adj @ adj has the same support as adj
+    reach = (adj.astype(np.int64) @ adj.astype(np.int64)) > 0
+    return bool((reach == adj).all())
+
+
+def founder_matrix(rng, n, W, n_founder, p_founder, p_private):
+    anc = rng.integers(0, 2, size=W, dtype=np.uint8)
+    f = np.repeat(anc[None, :], n_founder, axis=0)
+    f ^= (rng.random((n_founder, W)) < p_founder).astype(np.uint8)
+    who = rng.integers(0, n_founder, size=n)
+    m = f[who].copy()
+    if p_private > 0:
+        m ^= (rng.random((n, W)) < p_private).astype(np.uint8)
+    return m, who
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--ref", default="/root/reference")
+    ap.add_argument("--out", default=os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden"))
+    args = ap.parse_args()
+    sc = os.path.join(args.ref, "scripts")
+    pica2 = load("ref_pica2", os.path.join(sc, "pica2.py"))
+    hfst = load("ref_hfst", os.path.join(sc, "h-fst.py"))
+    tjd = load("ref_tj_d", os.path.join(sc, "tj_d.py"))
+    af = load("ref_af", os.path.join(sc, "af.py"))
+    os.makedirs(args.out, exist_ok=True)
+    meta = {"python": sys.version.split()[0], "PYTHONHASHSEED": os.environ.get("PYTHONHASHSEED", "random"),
+            "generator": "oracle/gen_golden.py", "reference": "pangenome/impop @ /root/reference (2025-10-31 snapshot)"}
+
+    # ------------------------------------------------------------------ tajima
+    taj = []
+    cases = [(446, 20.0, 0.59146123),  # doc/how_tjd.md:45
+             (465, 2543.0, 1.234e-06), (465, 2543.0, 61.7), (2, 1.0, 0.5), (3, 0.0, 0.0), (10, 1.0, 0.0),
+             (8, 17.0, 3.3e-07), (100, 1e6, 2.5e-3), (465, 1.0, 1e-8), (5000, 12345.0, 0.001)]
+    rng = np.random.default_rng(7)
+    for _ in range(30):
+        cases.append((int(rng.integers(2, 3000)), float(rng.integers(0, 100000)), float(rng.random() * 10.0 ** int(rng.integers(-9, 2)))))
+    for n, S, pi in cases:
+        D, c = tjd.tajimas_d(n, S, pi, return_components=True)
+        taj.append({"n": n, "S": hx(S), "pi": hx(pi), "D": hx(D),
+                    "comps": [hx(v) for v in (c.a1, c.a2, c.b1, c.b2, c.c1, c.c2, c.e1, c.e2, c.numerator, c.denominator)]})
+    errs = []
+    for n, S, pi in [(1, 1.0, 0.1), (5, -1.0, 0.1), (5, 1.0, -0.1)]:
+        try:
+            tjd.tajimas_d(n, S, pi)
+            errs.append({"n": n, "S": S, "pi": pi, "error": None})
+        except ValueError as e:
+            errs.append({"n": n, "S": S, "pi": pi, "error": str(e)})
+    json.dump({"meta": meta, "cases": taj, "errors": errs}, open(os.path.join(args.out, "tajima.json"), "w"), indent=1)
+
+    # ------------------------------------------- the 6-sequence table
+    # data rows of scripts/hudson/example_fst_methods.py:8-24 (a data table, not code)
+    rows6 = [("seq1_popA", "seq2_popA", 0.9995), ("seq1_popA", "seq3_popA", 0.9993), ("seq2_popA", "seq3_popA", 0.9998),
+             ("seq1_popA", "seq4_popB", 0.9950), ("seq1_popA", "seq5_popB", 0.9948), ("seq1_popA", "seq6_popB", 0.9952),
+             ("seq2_popA", "seq4_popB", 0.9951), ("seq2_popA", "seq5_popB", 0.9949), ("seq2_popA", "seq6_popB", 0.9953),
+             ("seq3_popA", "seq4_popB", 0.9949), ("seq3_popA", "seq5_popB", 0.9947), ("seq3_popA", "seq6_popB", 0.9951),
+             ("seq4_popB", "seq5_popB", 0.9996), ("seq4_popB", "seq6_popB", 0.9994), ("seq5_popB", "seq6_popB", 0.9997)]
+    with tempfile.TemporaryDirectory() as td:
+        p = os.path.join(td, "example_similarities.tsv")
+        with open(p, "w") as f:
+            f.write("group.a\tgroup.b\testimated.identity\n")
+            for a, b, v in rows6:
+                f.write(f"{a}\t{b}\t{v!r}\n")
+        d, elements, pc = pica2.read_similarity_file(p)
+        six = {"rows": [[a, b, hx(v)] for a, b, v in rows6], "pica2": [], "hfst": [], "af": []}
+        el6 = sorted(elements)
+        dense6 = np.eye(6)
+        for a, b, v in rows6:
+            dense6[el6.index(a), el6.index(b)] = dense6[el6.index(b), el6.index(a)] = v
+        for thr in (1.0, 0.9996, 0.999, 0.99):
+            for rd in (None, 3):
+                if not is_equivalence(dense6, thr, rd):
+                    continue  # seed-order dependent in the reference: no golden
+                pi, ps = pica2.analyze_similarity_matrix(dict(d), set(elements), pc, thr, 1000, io.StringIO(), rd)
+                six["pica2"].append({"threshold": hx(thr), "round": rd, "L": 1000, "pi": hx(pi), "pi_site": hx(ps)})
+        A = {"seq1_popA", "seq2_popA", "seq3_popA"}
+        B = {"seq4_popB", "seq5_popB", "seq6_popB"}
+        hd, hs = hfst.read_similarity_file(p)
+        for L, rd in ((None, None), (1000, None), (1000000, 3)):
+            r = hfst.calculate_fst(hd, set(A), set(B), L, rd)
+            six["hfst"].append({"L": L, "round": rd, "out": {k: hx(v) for k, v in r.items()}})
+        rows, samples = af.load_pairs(p)
+        for thr in (0.999, 0.9996, 1.0, 0.99):
+            cl = af.cluster(rows, samples, thr)
+            six["af"].append({"threshold": hx(thr), "clusters": [sorted(c) for c in cl]})
+        # CLI-level goldens (stdout text) for the drop-in scripts
+        pa, pb = os.path.join(td, "pop_A.txt"), os.path.join(td, "pop_B.txt")
+        open(pa, "w").write("seq1_popA\nseq2_popA\nseq3_popA\n")
+        open(pb, "w").write("seq4_popB\nseq5_popB\nseq6_popB\n")
+        def run(argv):
+            r = subprocess.run([sys.executable, "-B"] + argv, capture_output=True, text=True, cwd=td)
+            return {"argv": [os.path.basename(a) if a.startswith(td) or a.startswith(sc) else a for a in argv],
+                    "stdout": r.stdout, "rc": r.returncode}
+        six["cli"] = {
+            "pica2": [run([os.path.join(sc, "pica2.py"), p, "-t", t, "-l", "1000", "-d", td] + (["-r", r] if r else []))
+                      for t, r in (("0.999", "5"), ("1.0", None), ("0.9996", "4"), ("0.99", None))]
+                     + [run([os.path.join(sc, "pica2.py"), p, "-t", "0.999", "-d", td])],
+            # NB: bare names become the prefix 'seq1_popA#' (h-fst.py:57-61) and match nothing -> rc 1
+            "hfst": [run([os.path.join(sc, "h-fst.py"), p, "-a", pa, "-b", pb, "-l", "1000000", "-d", td])],
+            "tj_d": [run([os.path.join(sc, "tj_d.py"), "-n", "446", "-p", "0.59146123", "-S", "20"]),
+                     run([os.path.join(sc, "tj_d.py"), "-n", "465", "-p", "0.00000123", "-S", "2543", "--show-components"]),
+                     run([os.path.join(sc, "tj_d.py"), "-n", "10", "-p", "0.1", "-S", "0"])],
+            "af": [run([os.path.join(sc, "af.py"), "--input", p, "--threshold", "0.999"]),
+                   run([os.path.join(sc, "af.py"), "--input", p, "--threshold", "0.9996"])],
+        }
+    json.dump({"meta": meta, **six}, open(os.path.join(args.out, "six_seq.json"), "w"), indent=1)
+
+    # ------------------------------------------ population-name expansion (a6)
+    seqs = ["HG00097#1#CM094061.1:100-200", "HG00097#2#CM094062.1:100-200", "HG01891#1#JA1:5-9", "HG01891#2#JA2:5-9",
+            "NA12878#1#c:1-2", "NA128#1#c:1-2", "CHM13#0#chr1:100-200"]
+    raw = ["HG00097_hap1_hprc_r2_v1.0.1", "HG01891_pat_hprc_r2_v1.0.1", "HG01891_mat", "NA128", "NA12878#1", "CHM13#0#",
+           "missing_sample", "", "#comment", "  HG00097_hap2  ", "NA12878#1#c:1-2"]
+    canon = [hfst.canonicalize_identifier(r) for r in raw]
+    exp, missing = hfst.expand_population(raw, set(seqs))
+    json.dump({"meta": meta, "sequences": seqs, "raw": raw, "canonical": canon, "expanded": sorted(exp), "missing": missing},
+              open(os.path.join(args.out, "popnames.json"), "w"), indent=1)
+
+    # ------------------------------------------------ bit-matrix -> statistics
+    rng = np.random.default_rng(20251031)
+    mats = []
+    specs = [
+        # name, n, W, founders, p_founder, p_private, L
+        ("n8_w1000", 8, 1000, 3, 0.02, 0.002, 1000),     # BASELINE config 1 scale (8 haplotypes)
+        ("n61_w777", 61, 777, 5, 0.03, 0.004, 777),
+        ("n24_w300_clones", 24, 300, 4, 0.05, 0.0, 300),   # exact clones: '>thr' is an equivalence relation
+        ("n40_w2000_clones", 40, 2000, 6, 0.01, 0.0, 50000),
+        ("n130_w640", 130, 640, 8, 0.02, 0.003, 640),    # >128 haplotypes: second mask word
+    ]
+    for name, n, W, nf, pf, pp, L in specs:
+        m, who = founder_matrix(rng, n, W, nf, pf, pp)
+        names = names_for(n, "chr1", 0, W)
+        I = np_counts(m)
+        inA = np.zeros(n, dtype=np.uint8)
+        inB = np.zeros(n, dtype=np.uint8)
+        perm = rng.permutation(n)
+        inA[perm[: n // 3]] = 1
+        inB[perm[n // 3: n // 3 + n // 4]] = 1
+        rec = {"name": name, "n": n, "W": W, "L": L, "names": names, "bits_u64_b64": b64(pack_rows(m)),
+               "in_a": inA.tolist(), "in_b": inB.tolist(), "founder_of": who.tolist(),
+               "S_all": int(((m.sum(0) > 0) & (m.sum(0) < n)).sum()), "I_b64": b64(I.astype(np.int64)), "kinds": {}}
+        for kind in ("match", "dice"):
+            sim = np_identity(I, W, kind)
+            d = sim_dict(sim, names)
+            A = {names[i] for i in range(n) if inA[i]}
+            B = {names[i] for i in range(n) if inB[i]}
+            out = {"pica2": [], "hfst": [], "af": []}
+            thr_list = [1.0, 1.5]
+            offdiag = sim[~np.eye(n, dtype=bool)]
+            for thr in (0.999, 0.99, float(np.median(offdiag)), float(offdiag.max()) - 1e-12):
+                thr_list.append(thr)
+            for thr in thr_list:
+                for rd in (None, 5, 2):
+                    eq = is_equivalence(sim, thr, rd)
+                    if not eq:
+                        continue  # seed-order dependent in the reference: no golden
+                    for Lx in (L, None):
+                        pi, ps = pica2.analyze_similarity_matrix(dict(d), set(names), len(d), thr, Lx, io.StringIO(), rd)
+                        out["pica2"].append({"threshold": hx(thr), "round": rd, "L": Lx, "pi": hx(pi), "pi_site": hx(ps)})
+            for Lx, rd in ((L, None), (None, None), (L, 5), (L, 3)):
+                r = hfst.calculate_fst(d, set(A), set(B), Lx, rd)
+                out["hfst"].append({"L": Lx, "round": rd, "out": {k: hx(v) for k, v in r.items()}})
+            # overlapping populations (h-fst.py:181-185)
+            Bov = set(B) | set(list(A)[:2])
+            r = hfst.calculate_fst(d, set(A), set(Bov), L, None)
+            out["hfst_overlap"] = {"extra_in_b": sorted(list(A)[:2]), "L": L, "out": {k: hx(v) for k, v in r.items()}}
+            rows = [(a.split(":", 1)[0], b.split(":", 1)[0], v) for (a, b), v in d.items()]
+            samples = sorted({a for a, _, _ in rows} | {b for _, b, _ in rows})
+            for thr in (1.0, 0.999, float(np.median(offdiag)), 0.0):
+                cl = af.cluster(rows, samples, thr)
+                out["af"].append({"threshold": hx(thr), "clusters": [sorted(c) for c in cl]})
+            rec["kinds"][kind] = out
+        # full chain as wired by run_tajd.sh:166-180 on the `match` identity at t>=1
+        sim = np_identity(I, W, "match")
+        pi, ps = pica2.analyze_similarity_matrix(sim_dict(sim, names), set(names), 0, 1.0, L, io.StringIO(), None)
+        pi_text = f"{ps:.8f}"  # pica2.py:226 -> run_tajd.sh:174
+        D = tjd.tajimas_d(n, float(rec["S_all"]), float(pi_text))
+        rec["tajd_chain"] = {"pi_text": pi_text, "S": rec["S_all"], "n": n, "D": hx(D)}
+        mats.append(rec)
+    json.dump({"meta": meta, "matrices": mats}, open(os.path.join(args.out, "bitmatrix.json"), "w"), indent=1)
+
+    # -------------------------- CLI goldens on a PanSN-named .sim (n8_w1000, match)
+    m8 = mats[0]
+    bits8 = np.frombuffer(base64.b64decode(m8["bits_u64_b64"]), dtype=np.uint64).reshape(m8["n"], -1)
+    m01 = np.unpackbits(bits8.view(np.uint8), axis=1, bitorder="little")[:, : m8["W"]]
+    sim8 = np_identity(np_counts(m01), m8["W"], "match")
+    with tempfile.TemporaryDirectory() as td:
+        p = os.path.join(td, "win8.sim")
+        lines = ["group.a\tgroup.b\tgroup.a.length\tgroup.b.length\tintersection\testimated.identity"]
+        for i in range(8):
+            for j in range(8):  # impg-style: all ordered pairs, extra columns ignored (pica2.py:22)
+                lines.append(f"{m8['names'][i]}\t{m8['names'][j]}\t1000\t1000\t0\t{float(sim8[i, j])!r}")
+        open(p, "w").write("\n".join(lines) + "\n")
+        pa, pb = os.path.join(td, "popA.txt"), os.path.join(td, "popB.txt")
+        open(pa, "w").write("# population A\nS0000_hap1_hprc_r2_v1.0.1\nS0001\n\n")
+        open(pb, "w").write("S0002_mat_hprc_r2_v1.0.1\nS0003#2\nS0002_pat\nNOPE_hap1\n")
+        def run2(argv):
+            r = subprocess.run([sys.executable, "-B"] + argv, capture_output=True, text=True, cwd=td)
+            return {"argv": [os.path.basename(a) if a.startswith(td) or a.startswith(sc) else a for a in argv],
+                    "stdout": r.stdout, "stderr": r.stderr.replace(td, "<TMP>"), "rc": r.returncode}
+        cli = {"sim_text": open(p).read(), "popA": open(pa).read(), "popB": open(pb).read(),
+               "pica2": [run2([os.path.join(sc, "pica2.py"), p, "-t", t, "-l", "1000", "-d", td] + (["-r", r] if r else []))
+                         for t, r in (("1.0", None), ("0.999", "5"), ("0.99", None))],
+               "hfst": [run2([os.path.join(sc, "h-fst.py"), p, "-a", pa, "-b", pb, "-l", "1000", "-d", td]),
+                        run2([os.path.join(sc, "h-fst.py"), p, "-a", pa, "-b", pb, "-d", td, "-r", "4"]),
+                        run2([os.path.join(sc, "h-fst.py"), p, "-a", pa, "-b", pa, "-d", td])],
+               "af": [run2([os.path.join(sc, "af.py"), "--input", p, "--threshold", "1.0"]),
+                      run2([os.path.join(sc, "af.py"), "--input", p, "--threshold", "0.99"])],
+               "errors": [run2([os.path.join(sc, "pica2.py"), os.path.join(td, "nope.sim"), "-d", td]),
+                          run2([os.path.join(sc, "h-fst.py"), os.path.join(td, "nope.sim"), "-a", pa, "-b", pb, "-d", td])]}
+        bad = os.path.join(td, "bad.sim")
+        open(bad, "w").write("a\tb\tc\nx\ty\t0.5\n")
+        cli["errors"].append(run2([os.path.join(sc, "pica2.py"), bad, "-d", td]))
+        bad2 = os.path.join(td, "bad2.sim")
+        open(bad2, "w").write("group.a\tgroup.b\testimated.identity\nx\ty\tzzz\n")
+        cli["errors"].append(run2([os.path.join(sc, "pica2.py"), bad2, "-d", td]))
+        # is pica2 @ t=0.999 -r 5 order-independent on this table?
+        cli["pica2_equivalence"] = [is_equivalence(sim8, 1.0, None), is_equivalence(sim8, 0.999, 5), is_equivalence(sim8, 0.99, None)]
+    json.dump({"meta": meta, **cli}, open(os.path.join(args.out, "cli_pansn.json"), "w"), indent=1)
+
+    # ---------------------------------------------- missing pairs / ragged .sim
+    n = 7
+    names = names_for(n)
+    rng = np.random.default_rng(5)
+    sim = np.round(0.99 + 0.01 * rng.random((n, n)), 6)
+    sim = np.triu(sim, 1) + np.triu(sim, 1).T + np.eye(n)
+    d = sim_dict(sim, names)
+    drop = [(names[0], names[3]), (names[2], names[5]), (names[1], names[1])]
+    for k in drop:
+        d.pop(k, None)
+    rag = {"names": names, "sim": [[hx(v) for v in row] for row in sim], "dropped": [list(k) for k in drop], "pica2": [], "hfst": []}
+    for thr in (1.0,):
+        pi, ps = pica2.analyze_similarity_matrix(dict(d), set(names), len(d), thr, 500, io.StringIO(), None)
+        rag["pica2"].append({"threshold": hx(thr), "round": None, "L": 500, "pi": hx(pi), "pi_site": hx(ps)})
+    r = hfst.calculate_fst(d, set(names[:3]), set(names[3:]), 500, None)
+    rag["hfst"].append({"a": names[:3], "b": names[3:], "L": 500, "out": {k: hx(v) for k, v in r.items()}})
+    # degenerate inputs
+    pi0 = pica2.analyze_similarity_matrix({}, set(), 0, 1.0, 100, io.StringIO(), None)
+    pi1 = pica2.analyze_similarity_matrix({("x", "x"): 1.0}, {"x"}, 1, 1.0, 100, io.StringIO(), None)
+    rag["degenerate"] = {"empty": [hx(v) for v in pi0], "single": [hx(v) for v in pi1]}
+    json.dump({"meta": meta, **rag}, open(os.path.join(args.out, "ragged.json"), "w"), indent=1)
+    print("wrote goldens to", os.path.abspath(args.out))
+
+
+if __name__ == "__main__":
+    main()

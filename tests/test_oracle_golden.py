@@ -1,0 +1,162 @@
+"""CPU: the oracle (oracle/impop_oracle.c) against the goldens captured from the real
+reference (tests/golden/*.json, written by oracle/gen_golden.py) and the known answers
+of SURVEY.md §4.  This is what pins the oracle."""
+import math
+import random
+
+import numpy as np
+import pytest
+
+from conftest import fh, golden_bits, golden_counts, load_golden, rel_close
+
+TOL = 1e-12  # oracle vs reference: same fp64 operations, only summation order may differ
+
+
+def dense_from_rows(rows, names):
+    n = len(names)
+    ix = {s: i for i, s in enumerate(names)}
+    sim = np.full((n, n), np.nan)
+    for a, b, v in rows:
+        i, j = ix[a], ix[b]
+        sim[i, j] = sim[j, i] = v
+    return sim
+
+
+def test_py_round_matches_cpython(oracle):
+    rnd = random.Random(1)
+    vals = [0.999985, 0.999975, 0.99999499999, 0.5, 1.5, 2.5, 0.125, 1e-9, 0.0, 1.0, 0.99995, 0.9995, 2.675,
+            1.0000000000000002, 0.00002093456789, 123456.7890125]
+    for _ in range(20000):
+        k = rnd.randint(0, 3)
+        if k == 0:
+            vals.append(rnd.random())
+        elif k == 1:
+            vals.append(1.0 - rnd.random() * 1e-3)
+        elif k == 2:
+            vals.append(rnd.randint(0, 10 ** 6) / 10 ** rnd.randint(1, 7) + rnd.choice([0, 5e-7, 5e-6, 5e-9]))
+        else:
+            vals.append(rnd.random() * 10 ** rnd.randint(-10, 3))
+    for v in vals:
+        for nd in (0, 2, 3, 5, 8):
+            assert oracle.py_round(v, nd) == round(v, nd), (v, nd)
+
+
+def test_tajima_golden(oracle):
+    g = load_golden("tajima.json")
+    for c in g["cases"]:
+        D, comps = oracle.tajimas_d(c["n"], fh(c["S"]), fh(c["pi"]))
+        want = fh(c["D"])
+        assert (math.isnan(D) and math.isnan(want)) or D == want  # bit-exact: same op order
+        for got, w in zip(comps, c["comps"]):
+            w = fh(w)
+            assert (math.isnan(got) and math.isnan(w)) or got == w
+    for e in g["errors"]:
+        with pytest.raises(ValueError) as ei:
+            oracle.tajimas_d(e["n"], e["S"], e["pi"])
+        assert str(ei.value) == e["error"]
+
+
+def test_tajima_known_answer(oracle):
+    # doc/how_tjd.md:45
+    D, c = oracle.tajimas_d(446, 20.0, 0.59146123)
+    assert D == -1.9926482274156396
+    assert c[0] == 6.676413121751314 and c[1] == 1.6426893988793767
+
+
+def test_six_sequence_table(oracle):
+    g = load_golden("six_seq.json")
+    rows = [(a, b, fh(v)) for a, b, v in g["rows"]]
+    names = sorted({r[0] for r in rows} | {r[1] for r in rows})
+    sim = dense_from_rows(rows, names)
+    for c in g["pica2"]:
+        pi, ps, _, _ = oracle.pica2(sim, fh(c["threshold"]), c["L"], c["round"])
+        assert rel_close(pi, fh(c["pi"]), TOL) and rel_close(ps, fh(c["pi_site"]), TOL)
+    # SURVEY §4 values
+    pi, ps, _, G = oracle.pica2(sim, 1.0, 1000)
+    assert rel_close(pi, 0.0031799999999999966, TOL) and G == 6
+    pi, ps, _, G = oracle.pica2(sim, 0.999, 1000)
+    assert rel_close(pi, 0.0030000000000000027, TOL) and G == 2
+    assert oracle.pica2(sim, 0.99, 1000)[:2] == (0.0, 0.0)
+    inA = [1 if "popA" in s else 0 for s in names]
+    inB = [1 if "popB" in s else 0 for s in names]
+    for c in g["hfst"]:
+        out, _ = oracle.hfst(sim, inA, inB, c["L"], c["round"])
+        for k, v in c["out"].items():
+            assert rel_close(out[k], fh(v), TOL), (k, out[k], fh(v))
+    for c in g["af"]:
+        np.fill_diagonal(sim, np.nan)  # the table has no self rows
+        cl, K, sz = oracle.af_cluster(sim, fh(c["threshold"]))
+        got = [sorted(names[i] for i in range(len(names)) if cl[i] == k) for k in range(K)]
+        assert got == c["clusters"]
+
+
+def test_bitmatrix_goldens(oracle):
+    g = load_golden("bitmatrix.json")
+    for m in g["matrices"]:
+        n, W, L = m["n"], m["W"], m["L"]
+        bits = golden_bits(m)
+        I = oracle.pairwise_counts(bits, n, 0, W)
+        assert (I == golden_counts(m)).all()
+        inA, inB = np.array(m["in_a"], dtype=np.uint8), np.array(m["in_b"], dtype=np.uint8)
+        for kind, kid in (("match", 0), ("dice", 1)):
+            sim = oracle.identity(I, W, kid)
+            out = m["kinds"][kind]
+            for c in out["pica2"]:
+                pi, ps, _, _ = oracle.pica2(sim, fh(c["threshold"]), c["L"], c["round"])
+                assert rel_close(pi, fh(c["pi"]), TOL), (m["name"], kind, c)
+                assert rel_close(ps, fh(c["pi_site"]), TOL), (m["name"], kind, c)
+            for c in out["hfst"]:
+                r, _ = oracle.hfst(sim, inA, inB, c["L"], c["round"])
+                for k, v in c["out"].items():
+                    assert rel_close(r[k], fh(v), TOL, 1e-18), (m["name"], kind, k)
+            ov = out["hfst_overlap"]
+            inB2 = inB.copy()
+            for nm in ov["extra_in_b"]:
+                inB2[m["names"].index(nm)] = 1
+            r, _ = oracle.hfst(sim, inA, inB2, ov["L"], None)
+            for k, v in ov["out"].items():
+                assert rel_close(r[k], fh(v), TOL, 1e-18)
+            trunc = [s.split(":", 1)[0] for s in m["names"]]
+            for c in out["af"]:
+                cl, K, sz = oracle.af_cluster(sim, fh(c["threshold"]))
+                got = [sorted(trunc[i] for i in range(n) if cl[i] == k) for k in range(K)]
+                assert got == c["clusters"]
+        # window record: reference-style all-pairs chain vs site-count formulation
+        ones = oracle.pack_mask(np.ones(n, dtype=np.uint8))
+        ma, mb = oracle.pack_mask(inA), oracle.pack_mask(inB)
+        ra = oracle.window_allpairs(bits, n, 0, W, ones, ma, mb, L)
+        rs = oracle.window_sitecount(bits, n, 0, W, ones, ma, mb, L)
+        assert ra["s_all"] == rs["s_all"] == m["S_all"]
+        for k in ("n_sites", "s_all", "s_p", "s_a", "s_b", "sum_p", "sum_a", "sum_b", "sum_ab"):
+            assert ra[k] == rs[k]
+        for k in ("pi", "pi_site", "pi_a", "pi_b", "pi_xy", "dxy", "da", "fst", "tajima_d"):
+            assert rel_close(ra[k], rs[k], 1e-9, 1e-18), (m["name"], k, ra[k], rs[k])
+        # against the reference: pica2 @ t=1, hfst, and the run_tajd.sh-wired D
+        ref_p = [c for c in m["kinds"]["match"]["pica2"] if fh(c["threshold"]) == 1.0 and c["round"] is None and c["L"] == L][0]
+        assert rel_close(ra["pi"], fh(ref_p["pi"]), TOL) and rel_close(ra["pi_site"], fh(ref_p["pi_site"]), TOL)
+        ref_h = [c for c in m["kinds"]["match"]["hfst"] if c["L"] == L and c["round"] is None][0]["out"]
+        for k in ("fst", "pi_a", "pi_b", "pi_xy", "dxy", "da"):
+            assert rel_close(ra[k], fh(ref_h[k]), TOL, 1e-18)
+        assert rel_close(ra["tajima_d"], fh(m["tajd_chain"]["D"]), TOL)
+        assert rel_close(rs["tajima_d"], fh(m["tajd_chain"]["D"]), 1e-9)
+
+
+def test_ragged_and_degenerate(oracle):
+    g = load_golden("ragged.json")
+    names = g["names"]
+    sim = np.array([[fh(v) for v in row] for row in g["sim"]])
+    for a, b in g["dropped"]:
+        i, j = names.index(a), names.index(b)
+        sim[i, j] = sim[j, i] = np.nan
+    for c in g["pica2"]:
+        pi, ps, _, _ = oracle.pica2(sim, fh(c["threshold"]), c["L"], c["round"])
+        assert rel_close(pi, fh(c["pi"]), TOL) and rel_close(ps, fh(c["pi_site"]), TOL)
+    for c in g["hfst"]:
+        inA = [1 if s in c["a"] else 0 for s in names]
+        inB = [1 if s in c["b"] else 0 for s in names]
+        r, cnt = oracle.hfst(sim, inA, inB, c["L"], None)
+        for k, v in c["out"].items():
+            assert rel_close(r[k], fh(v), TOL)
+        assert cnt[5] == 2  # two between-pairs missing
+    assert oracle.pica2(np.zeros((0, 0)), 1.0, 100)[:2] == (fh(g["degenerate"]["empty"][0]), fh(g["degenerate"]["empty"][1]))
+    assert oracle.pica2(np.ones((1, 1)), 1.0, 100)[:2] == (fh(g["degenerate"]["single"][0]), fh(g["degenerate"]["single"][1]))

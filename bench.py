@@ -1,0 +1,220 @@
+#!/usr/bin/env python3
+"""bench.py — windows/sec of pi + Hudson Fst + Tajima's D, 465 haplotypes, 50 kb windows.
+
+One step = one pass of the hot path (impop_scan_plan_launch) over one chromosome-scale batch of
+synthetic windows that is already resident in HBM: BASELINE.json configs[1]/[2] — chr2-sized
+(4 854 windows x 50 000 sites), 465 haplotypes, populations A = rows 0-139, B = rows 140-239 —
+computing pi, pi_A, pi_B, Dxy, Fst, S and Tajima's D for every window in the same pass.
+
+    python bench.py --gpus N --steps K --warmup W
+
+N > 1 is launched by torch.distributed.run, one rank per GPU; every rank holds its own
+chromosome shard (weak scaling, no data-path collective) and the per-window records are
+all-gathered once per step over RCCL.  Rank 0 prints ONE JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s is what a copy achieves
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def cpu_baseline(bm, windows, in_a, in_b, budget_s=12.0):
+    """Time the CPU oracle (oracle/impop_oracle.c, the restated reference algorithm: all-pairs
+    Hamming -> identity -> pica2/h-fst/tj_d) on a bounded sample of the SAME windows, one host
+    core.  Also time the oracle's site-count formulation (the algorithm the GPU kernel uses)."""
+    import numpy as np
+
+    from oracle import oracle as orc
+    orc.build()
+    n = bm.n_hap
+    ones = orc.pack_mask(np.ones(n, np.uint8))
+    ma, mb = orc.pack_mask(in_a), orc.pack_mask(in_b)
+    t_all, n_all = 0.0, 0
+    t_sc, n_sc = 0.0, 0
+    first = None
+    i = 0
+    while t_all < budget_s and i < len(windows):
+        w = windows[i]
+        s0, s1 = int(w["site_begin"]), int(w["site_end"])
+        bits = bm.download(s0, s1)
+        t0 = time.perf_counter()
+        rec = orc.window_allpairs(bits, n, 0, s1 - s0, ones, ma, mb, int(w["seq_len"]))
+        t_all += time.perf_counter() - t0
+        n_all += 1
+        if first is None:
+            first = rec
+        i += 1
+    # site-count port on site-major words (conversion not timed: the GPU's layout is not timed either)
+    j = 0
+    while t_sc < budget_s / 2 and j < len(windows):
+        w = windows[j]
+        s0, s1 = int(w["site_begin"]), int(w["site_end"])
+        bits = bm.download(s0, s1)
+        sm = orc.to_sitemajor(bits, n, s1 - s0)
+        t0 = time.perf_counter()
+        orc.site_scan_sitemajor(sm, n, 0, s1 - s0, ones, ma, mb)
+        t_sc += time.perf_counter() - t0
+        n_sc += 1
+        j += 1
+    return {
+        "value": n_all / t_all if t_all > 0 else None, "unit": "windows/s", "cores": 1, "kind": "port",
+        "sample": f"first {n_all} windows of the timed workload through oracle_window_allpairs "
+                  f"(all-pairs Hamming + pica2/h-fst/tj_d restatement, gcc -O2, 1 thread, {t_all:.1f} s)",
+        "sitecount_port": {"value": n_sc / t_sc if t_sc > 0 else None, "unit": "windows/s", "cores": 1,
+                           "sample": f"{n_sc} windows, oracle_site_scan_sitemajor (integer sums only), {t_sc:.1f} s"},
+        "reference_python_measured_in_build_container": "0.67-0.91 s/window for pica2.py alone (BASELINE.md §2)",
+    }, first
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--n-hap", type=int, default=465)
+    ap.add_argument("--window", type=int, default=50000)
+    ap.add_argument("--n-windows", type=int, default=4854, help="per GPU; 4854 = chr2 (242.7 Mb) in 50 kb windows")
+    ap.add_argument("--tile-blocks", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            log(f"bench.py: --gpus {args.gpus} needs `python -m torch.distributed.run --nproc-per-node {args.gpus} ...`")
+            sys.exit(2)
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    import impop_amd
+
+    if not torch.cuda.is_available():
+        log("bench.py: no GPU visible; impop_amd has no CPU path to measure")
+        sys.exit(2)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    stream = torch.cuda.current_stream(dev)
+    ctx = impop_amd.Context(local_rank, stream=stream.cuda_stream)
+    n, W, NW = args.n_hap, args.window, args.n_windows
+    n_site = W * NW
+    t0 = time.perf_counter()
+    bm = ctx.synthetic(n, n_site, seed=20251031 + rank)  # each rank: its own chromosome shard
+    ctx.synchronize()
+    if rank == 0:
+        log(f"[bench] synthetic matrix {n} x {n_site} sites = {bm.device_bytes / 1e9:.2f} GB in HBM "
+            f"({bm.bytes_per_site} B/site) generated in {time.perf_counter() - t0:.2f} s")
+    windows = impop_amd.fixed_windows(n_site, W)
+    in_a = np.zeros(n, np.uint8); in_a[: min(140, n)] = 1
+    in_b = np.zeros(n, np.uint8); in_b[min(140, n): min(240, n)] = 1
+    plan = bm.plan(windows, None, in_a, in_b, tile_blocks=args.tile_blocks)
+    local = torch.empty(NW * 128, dtype=torch.uint8, device=dev)
+    gathered = torch.empty(world * NW * 128, dtype=torch.uint8, device=dev) if world > 1 else None
+
+    def step():
+        plan.launch(local.data_ptr())
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, local)
+
+    # ---- parity gate before timing (rank 0): GPU records vs the CPU oracle on sampled windows
+    step()
+    torch.cuda.synchronize(dev)
+    recs = np.frombuffer(local.cpu().numpy().tobytes(), dtype=impop_amd.STATS_DTYPE)
+    cpu, first = None, None
+    if rank == 0:
+        from oracle import oracle as orc
+        orc.build()
+        ones = orc.pack_mask(np.ones(n, np.uint8))
+        for wi in sorted({0, NW // 2, NW - 1}):
+            s0, s1 = int(windows[wi]["site_begin"]), int(windows[wi]["site_end"])
+            want = orc.window_sitecount(bm.download(s0, s1), n, 0, s1 - s0, ones, orc.pack_mask(in_a), orc.pack_mask(in_b),
+                                        int(windows[wi]["seq_len"]))
+            got = recs[wi]
+            for k in ("n_sites", "s_all", "s_p", "s_a", "s_b", "sum_p", "sum_a", "sum_b", "sum_ab"):
+                assert int(got[k]) == int(want[k]), ("parity gate", wi, k, int(got[k]), int(want[k]))
+            for k in ("pi", "pi_site", "pi_a", "pi_b", "pi_xy", "dxy", "da", "fst", "tajima_d"):
+                a, b = float(got[k]), float(want[k])
+                assert abs(a - b) <= 1e-9 * max(abs(a), abs(b)), ("parity gate", wi, k, a, b)
+        log("[bench] parity gate passed (3 windows vs CPU oracle: integers exact, doubles <= 1e-9 rel)")
+
+    # ---- timed region
+    for _ in range(args.warmup):
+        step()
+    plan.timing(True)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    elapsed = time.perf_counter() - t0
+    kern_ms, launches = plan.elapsed()
+    plan.timing(False)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        k = torch.tensor([kern_ms], dtype=torch.float64, device=dev)
+        dist.all_reduce(k, op=dist.ReduceOp.MAX)
+        kern_ms = float(k.item())
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu, first = cpu_baseline(bm, windows, in_a, in_b)
+
+    if rank == 0:
+        total_windows = NW * world * args.steps
+        value = total_windows / elapsed
+        algo_bytes = n * n_site / 8.0                      # n*W/8 per window x windows per launch
+        avg_kern_s = (kern_ms / 1e3) / max(launches, 1)
+        achieved = algo_bytes / avg_kern_s / 1e9
+        out = {
+            "metric": "windows/sec (pi+Fst+D) for 465-hap HPRC, 50 kb windows",
+            "value": value, "unit": "windows/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+            "config": {"workload": f"chr2-scale scan: {NW} windows x {W} sites per GPU, {n} haplotypes, pi + Hudson Fst "
+                                   f"(A=140 vs B=100) + Tajima's D + S in one pass; BASELINE configs[1]+[2]",
+                       "n_hap": n, "window_sites": W, "windows_per_gpu": NW, "bytes_per_site": bm.bytes_per_site,
+                       "layout": "SB64 site-blocked wave-interleaved bit matrix", "tiles": plan.n_tiles,
+                       "parallelism": f"windows sharded over {world} GPU(s), one all_gather of records per step"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "scan_tiles_kernel<15,false>", "kernel_ms_avg": avg_kern_s * 1e3,
+                         "algorithmic_bytes_per_launch": algo_bytes, "layout_bytes_per_launch": plan.bytes_streamed,
+                         "layout_GBps": plan.bytes_streamed / avg_kern_s / 1e9},
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(out), flush=True)
+    plan.destroy()
+    bm.free()
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

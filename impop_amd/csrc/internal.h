@@ -1,0 +1,100 @@
+// internal.h — shared host-side structures of libimpop_hip.so (not part of the ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string>
+#include <vector>
+
+#include "../../include/impop_hip.h"
+
+#define IMPOP_API extern "C" __attribute__((visibility("default")))
+
+namespace impop {
+
+void set_error(const char *fmt, ...) __attribute__((format(printf, 1, 2)));
+int hip_fail(hipError_t e, const char *what, const char *file, int line);
+
+#define HIP_TRY(expr)                                                        \
+    do {                                                                     \
+        hipError_t _e = (expr);                                              \
+        if (_e != hipSuccess) return impop::hip_fail(_e, #expr, __FILE__, __LINE__); \
+    } while (0)
+
+#define REQUIRE(cond, ...)                 \
+    do {                                   \
+        if (!(cond)) {                     \
+            impop::set_error(__VA_ARGS__); \
+            return IMPOP_E_INVALID;        \
+        }                                  \
+    } while (0)
+
+// ---- SB64: site-blocked, wave-interleaved layout --------------------------------
+// The site axis is cut into blocks of 64 sites (one wavefront).  A site holds
+// wps = ceil(n_hap/32) dwords (dword k = haplotypes 32k..32k+31).  Inside a block the
+// dwords are stored in 16-byte granules interleaved over the 64 sites, so that lane l
+// of a wave (= site 64b+l) reads its granule g with ONE fully coalesced 1 KiB
+// global_load_dwordx4:
+//     dword(b, l, k) @ b*64*wps + (k/4)*256 + l*4 + (k%4)          for k/4 < G-1
+//     dword(b, l, k) @ b*64*wps + (G-1)*256 + l*r + (k - 4(G-1))    last granule, r dwords
+// with G = ceil(wps/4), r = wps - 4(G-1) in 1..4.  Bytes per site = 4*wps exactly
+// (60 B for 465 haplotypes: 3.2 % above the algorithmic n/8).
+struct SbGeom {
+    uint32_t n_hap = 0;
+    uint32_t wps = 0;    // dwords per site
+    uint32_t G = 0;      // granules per site
+    uint32_t r = 0;      // dwords in the last granule
+    uint64_t n_site = 0;
+    uint64_t n_block = 0;  // ceil(n_site/64)
+};
+
+}  // namespace impop
+
+struct impop_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    char arch[128] = {0};
+    int n_cu = 0;
+    // cached Tajima constants on the device, keyed by n (8 doubles: a1,a2,b1,b2,c1,c2,e1,e2)
+    double *d_taj = nullptr;
+    int64_t taj_n = -1;
+    // growable scratch
+    void *scratch = nullptr;
+    size_t scratch_bytes = 0;
+    void *pinned = nullptr;
+    size_t pinned_bytes = 0;
+};
+
+struct impop_matrix {
+    impop::SbGeom g;
+    uint32_t *d_sb = nullptr;   // SB64 layout, n_block*64*wps dwords
+    uint64_t sb_bytes = 0;
+    uint32_t *d_hm = nullptr;   // hap-major: n_hap_pad rows x hm_stride dwords (optional)
+    uint64_t hm_stride = 0;     // dwords per row (multiple of 4), covers n_block*64 sites
+    uint32_t n_hap_pad = 0;     // rows padded to a multiple of 64 (zero rows)
+    uint64_t hm_bytes = 0;
+    int device = 0;
+};
+
+namespace impop {
+int ctx_scratch(impop_ctx *ctx, size_t bytes, void **out);
+int ctx_pinned(impop_ctx *ctx, size_t bytes, void **out);
+int ensure_tajima_consts(impop_ctx *ctx, int64_t n);  // fills ctx->d_taj for n (device kernel)
+
+// layout.hip
+int launch_hm_to_sb(impop_ctx *ctx, const uint32_t *d_hm, uint64_t hm_stride, const SbGeom &g, uint32_t *d_sb);
+int launch_sb_to_hm(impop_ctx *ctx, const uint32_t *d_sb, const SbGeom &g, uint64_t blk_begin, uint64_t blk_end,
+                    uint32_t *d_hm, uint64_t hm_stride, uint32_t n_rows);
+
+// stats.hip — "problem" = one identity matrix (dense or derived from Gram counts)
+struct SimSource {
+    const double *dense;    // n x ld doubles (NaN = missing) or nullptr
+    const int32_t *gram;    // ldg x ldg int32 intersection counts (upper tiles valid, see pairwise.hip)
+    uint32_t ld;            // leading dimension of dense / gram
+    uint32_t n;             // number of elements in the full matrix
+    uint64_t W;             // sites in the window (gram mode)
+    int kind;               // IMPOP_IDENTITY_*
+    int round_digits;       // <0 none
+};
+}  // namespace impop

@@ -1,0 +1,349 @@
+// layout.hip — presence-matrix residency: upload, SB64 <-> hap-major transposition on the
+// device (wave64 readlane / ballot bit transposes), the synthetic generator and download.
+#include <string.h>
+
+#include <vector>
+
+#include "device_utils.h"
+#include "internal.h"
+
+namespace impop {
+
+__host__ __device__ inline uint64_t sb_index(uint32_t wps, uint32_t G, uint32_t r, uint64_t b, uint32_t l,
+                                             uint32_t k) {
+    const uint32_t g = k >> 2;
+    const uint64_t base = b * 64ull * wps;
+    return (g + 1 < G) ? base + (uint64_t)g * 256 + l * 4 + (k & 3)
+                       : base + (uint64_t)(G - 1) * 256 + (uint64_t)l * r + (k - 4 * (G - 1));
+}
+
+static SbGeom make_geom(uint32_t n_hap, uint64_t n_site) {
+    SbGeom g;
+    g.n_hap = n_hap;
+    g.wps = (n_hap + 31) / 32;
+    g.G = (g.wps + 3) / 4;
+    g.r = g.wps - 4 * (g.G - 1);
+    g.n_site = n_site;
+    g.n_block = (n_site + 63) / 64;
+    return g;
+}
+
+// ---- hap-major -> SB64 --------------------------------------------------------------
+// One wave per 64-site block.  For each 32-haplotype dword k, lanes 0..31 fetch the
+// 64-site word of haplotype 32k+lane; v_readlane broadcasts each of them and every lane
+// (= site) picks its own bit: a 32x64 bit transpose in 32 readlane+bfe+lshl_or steps.
+__global__ __launch_bounds__(256) void hm_to_sb_kernel(const uint32_t *__restrict__ hm, uint64_t hm_stride,
+                                                       uint32_t n_rows, uint32_t wps, uint32_t G, uint32_t r,
+                                                       uint64_t n_block, uint32_t *__restrict__ sb) {
+    const uint32_t lane = threadIdx.x & 63;
+    const uint64_t b = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= n_block) return;  // wave-uniform
+    for (uint32_t k = 0; k < wps; ++k) {
+        uint64_t w = 0;
+        const uint32_t row = 32 * k + lane;
+        if (lane < 32 && row < n_rows) {
+            const uint32_t *p = hm + (uint64_t)row * hm_stride + 2 * b;
+            w = (uint64_t)p[0] | ((uint64_t)p[1] << 32);
+        }
+        uint32_t out = 0;
+#pragma unroll
+        for (int j = 0; j < 32; ++j) {
+            const uint64_t wj = __shfl(w, j, 64);
+            out |= (uint32_t)((wj >> lane) & 1ull) << j;
+        }
+        sb[sb_index(wps, G, r, b, lane, k)] = out;
+    }
+}
+
+// ---- SB64 -> hap-major ---------------------------------------------------------------
+// One wave per block; lane = site.  __ballot of bit j of the site's dword k is exactly
+// the 64-site hap-major word of haplotype 32k+j.
+__global__ __launch_bounds__(256) void sb_to_hm_kernel(const uint32_t *__restrict__ sb, uint32_t wps, uint32_t G,
+                                                       uint32_t r, uint64_t blk_begin, uint64_t blk_end,
+                                                       uint32_t *__restrict__ hm, uint64_t hm_stride,
+                                                       uint32_t n_rows) {
+    const uint32_t lane = threadIdx.x & 63;
+    const uint64_t b = blk_begin + (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= blk_end) return;  // wave-uniform
+    for (uint32_t k = 0; k < wps; ++k) {
+        const uint32_t w = sb[sb_index(wps, G, r, b, lane, k)];
+        uint64_t keep = 0;
+#pragma unroll
+        for (int j = 0; j < 32; ++j) {
+            const uint64_t m = __ballot((w >> j) & 1u);
+            if (lane == (uint32_t)j) keep = m;
+        }
+        const uint32_t row = 32 * k + lane;
+        if (lane < 32 && row < n_rows) {
+            uint32_t *p = hm + (uint64_t)row * hm_stride + 2 * (b - blk_begin);
+            p[0] = (uint32_t)keep;
+            p[1] = (uint32_t)(keep >> 32);
+        }
+    }
+}
+
+// zero the bits of sites >= n_site in the last used dword pair of every hap-major row
+__global__ void hm_clear_tail_kernel(uint32_t *hm, uint64_t hm_stride, uint32_t n_rows, uint64_t n_site,
+                                     uint64_t n_dwords_used) {
+    const uint32_t row = blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= n_rows) return;
+    uint32_t *p = hm + (uint64_t)row * hm_stride;
+    const uint64_t first = n_site >> 5;
+    if (first < n_dwords_used) {
+        const uint32_t keepbits = (uint32_t)(n_site & 31);
+        p[first] &= keepbits ? ((1u << keepbits) - 1u) : 0u;
+        for (uint64_t d = first + 1; d < n_dwords_used; ++d) p[d] = 0;
+    }
+}
+
+int launch_hm_to_sb(impop_ctx *ctx, const uint32_t *d_hm, uint64_t hm_stride, const SbGeom &g, uint32_t *d_sb) {
+    if (g.n_block == 0) return IMPOP_OK;
+    const uint64_t grid = (g.n_block + 3) / 4;
+    REQUIRE(grid < 0x7FFFFFFFull, "matrix too long for one launch (%llu blocks)", (unsigned long long)g.n_block);
+    const uint32_t n_rows = (g.n_hap + 63) / 64 * 64;
+    hipLaunchKernelGGL(hm_to_sb_kernel, dim3((uint32_t)grid), dim3(256), 0, ctx->stream, d_hm, hm_stride, n_rows, g.wps,
+                       g.G, g.r, g.n_block, d_sb);
+    HIP_TRY(hipGetLastError());
+    return IMPOP_OK;
+}
+
+int launch_sb_to_hm(impop_ctx *ctx, const uint32_t *d_sb, const SbGeom &g, uint64_t blk_begin, uint64_t blk_end,
+                    uint32_t *d_hm, uint64_t hm_stride, uint32_t n_rows) {
+    if (blk_end <= blk_begin) return IMPOP_OK;
+    const uint64_t grid = (blk_end - blk_begin + 3) / 4;
+    REQUIRE(grid < 0x7FFFFFFFull, "range too long for one launch");
+    hipLaunchKernelGGL(sb_to_hm_kernel, dim3((uint32_t)grid), dim3(256), 0, ctx->stream, d_sb, g.wps, g.G, g.r, blk_begin,
+                       blk_end, d_hm, hm_stride, n_rows);
+    HIP_TRY(hipGetLastError());
+    return IMPOP_OK;
+}
+
+// ---- synthetic generator ---------------------------------------------------------------
+struct SynthDev {
+    uint64_t seed;
+    uint32_t n_founder;
+    uint32_t thr_founder;  // p_founder * 2^32
+    uint32_t thr_private;  // p_private_word * 2^32
+};
+
+// tables: fmask[f*wps + k] (haplotypes of founder f in dword k), then valid[k]
+__global__ __launch_bounds__(256) void synth_sb_kernel(SynthDev p, const uint32_t *__restrict__ tables, uint32_t wps,
+                                                       uint32_t G, uint32_t r, uint64_t n_block, uint64_t n_site,
+                                                       uint32_t *__restrict__ sb) {
+    const uint32_t lane = threadIdx.x & 63;
+    const uint64_t b = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= n_block) return;
+    const uint64_t s = b * 64 + lane;
+    const bool live = s < n_site;
+    const uint32_t anc = (synth_hash(p.seed, 1, s) & 1ull) ? 0xFFFFFFFFu : 0u;
+    uint32_t fl = 0;
+    for (uint32_t f = 0; f < p.n_founder; ++f)
+        if ((uint32_t)(synth_hash(p.seed, 2 + f, s) >> 32) < p.thr_founder) fl |= 1u << f;
+    const uint32_t *valid = tables + (uint64_t)p.n_founder * wps;
+    for (uint32_t k = 0; k < wps; ++k) {
+        uint32_t w = anc;
+        uint32_t m = fl;
+        while (m) {
+            const int f = __ffs(m) - 1;
+            m &= m - 1;
+            w ^= tables[(uint64_t)f * wps + k];
+        }
+        const uint64_t h = synth_hash(p.seed, 64 + k, s);
+        if ((uint32_t)(h >> 32) < p.thr_private) w ^= 1u << (uint32_t)(h & 31);
+        w &= valid[k];
+        sb[sb_index(wps, G, r, b, lane, k)] = live ? w : 0u;
+    }
+}
+
+static int alloc_matrix(impop_ctx *ctx, uint32_t n_hap, uint64_t n_site, bool want_hm, impop_matrix **out) {
+    impop_matrix *m = new impop_matrix();
+    m->g = make_geom(n_hap, n_site);
+    m->device = ctx->device;
+    m->n_hap_pad = (n_hap + 63) / 64 * 64;
+    m->sb_bytes = m->g.n_block * 64ull * m->g.wps * 4ull;
+    // one extra block of slack so software-pipelined kernels may prefetch one block past the end
+    hipError_t e = hipMalloc((void **)&m->d_sb, m->sb_bytes + 64ull * m->g.wps * 4ull + 256);
+    if (e != hipSuccess) {
+        delete m;
+        return hip_fail(e, "hipMalloc(SB64 matrix)", __FILE__, __LINE__);
+    }
+    e = hipMemsetAsync((char *)m->d_sb + m->sb_bytes, 0, 64ull * m->g.wps * 4ull + 256, ctx->stream);
+    if (e != hipSuccess) {
+        hipFree(m->d_sb);
+        delete m;
+        return hip_fail(e, "hipMemsetAsync", __FILE__, __LINE__);
+    }
+    if (want_hm) {
+        m->hm_stride = (m->g.n_block * 2 + 3) / 4 * 4;
+        if (m->hm_stride == 0) m->hm_stride = 4;
+        m->hm_bytes = (uint64_t)m->n_hap_pad * m->hm_stride * 4ull;
+        e = hipMalloc((void **)&m->d_hm, m->hm_bytes);
+        if (e != hipSuccess) {
+            hipFree(m->d_sb);
+            delete m;
+            return hip_fail(e, "hipMalloc(hap-major matrix)", __FILE__, __LINE__);
+        }
+    }
+    *out = m;
+    return IMPOP_OK;
+}
+
+}  // namespace impop
+
+using namespace impop;
+
+IMPOP_API int impop_matrix_upload(impop_ctx *ctx, const uint64_t *bits, uint32_t n_hap, uint64_t n_site,
+                                  uint64_t row_stride_words, uint32_t keep_flags, impop_matrix **out) {
+    REQUIRE(ctx && out, "impop_matrix_upload: ctx/out is NULL");
+    *out = nullptr;
+    REQUIRE(n_hap >= 1, "impop_matrix_upload: n_hap must be >= 1");
+    REQUIRE(n_hap <= (1u << 20), "impop_matrix_upload: n_hap %u too large", n_hap);
+    const uint64_t words = (n_site + 63) / 64;
+    REQUIRE(n_site == 0 || bits, "impop_matrix_upload: bits is NULL");
+    REQUIRE(row_stride_words >= words, "impop_matrix_upload: row_stride_words %llu < ceil(n_site/64) = %llu",
+            (unsigned long long)row_stride_words, (unsigned long long)words);
+    HIP_TRY(hipSetDevice(ctx->device));
+    impop_matrix *m = nullptr;
+    int rc = alloc_matrix(ctx, n_hap, n_site, true, &m);
+    if (rc) return rc;
+    auto fail = [&](int code) {
+        impop_matrix_free(ctx, m);
+        return code;
+    };
+    hipError_t e = hipMemsetAsync(m->d_hm, 0, m->hm_bytes, ctx->stream);
+    if (e != hipSuccess) return fail(hip_fail(e, "hipMemsetAsync", __FILE__, __LINE__));
+    if (words) {
+        e = hipMemcpy2DAsync(m->d_hm, m->hm_stride * 4ull, bits, row_stride_words * 8ull, words * 8ull, n_hap,
+                             hipMemcpyHostToDevice, ctx->stream);
+        if (e != hipSuccess) return fail(hip_fail(e, "hipMemcpy2DAsync(upload)", __FILE__, __LINE__));
+        hipLaunchKernelGGL(hm_clear_tail_kernel, dim3((m->n_hap_pad + 255) / 256), dim3(256), 0, ctx->stream, m->d_hm,
+                           m->hm_stride, m->n_hap_pad, n_site, words * 2);
+        if ((e = hipGetLastError()) != hipSuccess) return fail(hip_fail(e, "hm_clear_tail_kernel", __FILE__, __LINE__));
+    }
+    rc = launch_hm_to_sb(ctx, m->d_hm, m->hm_stride, m->g, m->d_sb);
+    if (rc) return fail(rc);
+    e = hipStreamSynchronize(ctx->stream);  // the caller may free `bits` on return
+    if (e != hipSuccess) return fail(hip_fail(e, "hipStreamSynchronize", __FILE__, __LINE__));
+    if (!(keep_flags & IMPOP_KEEP_HAP_MAJOR)) {
+        hipFree(m->d_hm);
+        m->d_hm = nullptr;
+        m->hm_bytes = 0;
+    }
+    *out = m;
+    return IMPOP_OK;
+}
+
+IMPOP_API int impop_matrix_synthetic(impop_ctx *ctx, uint32_t n_hap, uint64_t n_site, const impop_synth_params *p,
+                                     uint32_t keep_flags, impop_matrix **out) {
+    REQUIRE(ctx && out && p, "impop_matrix_synthetic: NULL argument");
+    *out = nullptr;
+    REQUIRE(n_hap >= 1 && n_hap <= (1u << 20), "impop_matrix_synthetic: bad n_hap %u", n_hap);
+    REQUIRE(p->n_founder >= 1 && p->n_founder <= 32, "impop_matrix_synthetic: n_founder must be 1..32");
+    REQUIRE(p->p_founder >= 0 && p->p_founder < 1 && p->p_private_word >= 0 && p->p_private_word < 1,
+            "impop_matrix_synthetic: probabilities must be in [0,1)");
+    HIP_TRY(hipSetDevice(ctx->device));
+    impop_matrix *m = nullptr;
+    const bool want_hm = (keep_flags & IMPOP_KEEP_HAP_MAJOR) != 0;
+    int rc = alloc_matrix(ctx, n_hap, n_site, want_hm, &m);
+    if (rc) return rc;
+    auto fail = [&](int code) {
+        impop_matrix_free(ctx, m);
+        return code;
+    };
+    const uint32_t wps = m->g.wps;
+    std::vector<uint32_t> tables((size_t)(p->n_founder + 1) * wps, 0u);
+    for (uint32_t h = 0; h < n_hap; ++h) {
+        const uint32_t f = (uint32_t)(synth_hash(p->seed, 1000, h) % p->n_founder);
+        tables[(size_t)f * wps + (h >> 5)] |= 1u << (h & 31);
+        tables[(size_t)p->n_founder * wps + (h >> 5)] |= 1u << (h & 31);
+    }
+    void *d_tab = nullptr;
+    rc = ctx_scratch(ctx, tables.size() * 4, &d_tab);
+    if (rc) return fail(rc);
+    hipError_t e = hipMemcpyAsync(d_tab, tables.data(), tables.size() * 4, hipMemcpyHostToDevice, ctx->stream);
+    if (e != hipSuccess) return fail(hip_fail(e, "hipMemcpyAsync(tables)", __FILE__, __LINE__));
+    SynthDev sp;
+    sp.seed = p->seed;
+    sp.n_founder = p->n_founder;
+    sp.thr_founder = (uint32_t)(p->p_founder * 4294967296.0);
+    sp.thr_private = (uint32_t)(p->p_private_word * 4294967296.0);
+    if (m->g.n_block) {
+        const uint64_t grid = (m->g.n_block + 3) / 4;
+        if (grid >= 0x7FFFFFFFull) {
+            set_error("impop_matrix_synthetic: too many sites");
+            return fail(IMPOP_E_INVALID);
+        }
+        hipLaunchKernelGGL(synth_sb_kernel, dim3((uint32_t)grid), dim3(256), 0, ctx->stream, sp, (const uint32_t *)d_tab,
+                           wps, m->g.G, m->g.r, m->g.n_block, n_site, m->d_sb);
+        if ((e = hipGetLastError()) != hipSuccess) return fail(hip_fail(e, "synth_sb_kernel", __FILE__, __LINE__));
+        if (want_hm) {
+            e = hipMemsetAsync(m->d_hm, 0, m->hm_bytes, ctx->stream);
+            if (e != hipSuccess) return fail(hip_fail(e, "hipMemsetAsync", __FILE__, __LINE__));
+            rc = launch_sb_to_hm(ctx, m->d_sb, m->g, 0, m->g.n_block, m->d_hm, m->hm_stride, m->n_hap_pad);
+            if (rc) return fail(rc);
+        }
+    }
+    e = hipStreamSynchronize(ctx->stream);  // `tables` (pageable) must stay alive until the copy is done
+    if (e != hipSuccess) return fail(hip_fail(e, "hipStreamSynchronize", __FILE__, __LINE__));
+    *out = m;
+    return IMPOP_OK;
+}
+
+IMPOP_API int impop_matrix_download(impop_ctx *ctx, const impop_matrix *m, uint64_t site_begin, uint64_t site_end,
+                                    uint64_t *out, uint64_t row_stride_words) {
+    REQUIRE(ctx && m, "impop_matrix_download: NULL argument");
+    REQUIRE(site_begin <= site_end && site_end <= m->g.n_site, "impop_matrix_download: bad site range [%llu,%llu)",
+            (unsigned long long)site_begin, (unsigned long long)site_end);
+    const uint64_t W = site_end - site_begin;
+    const uint64_t out_words = (W + 63) / 64;
+    REQUIRE(row_stride_words >= out_words, "impop_matrix_download: row_stride_words too small");
+    if (W == 0) return IMPOP_OK;
+    REQUIRE(out, "impop_matrix_download: out is NULL");
+    HIP_TRY(hipSetDevice(ctx->device));
+    const uint64_t b0 = site_begin / 64, b1 = (site_end + 63) / 64;
+    const uint64_t nb = b1 - b0;
+    const uint64_t stride = nb * 2;  // dwords per row in the temporary
+    const uint32_t n_rows = m->g.n_hap;
+    void *d_tmp = nullptr;
+    int rc = ctx_scratch(ctx, (size_t)n_rows * stride * 4, &d_tmp);
+    if (rc) return rc;
+    rc = launch_sb_to_hm(ctx, m->d_sb, m->g, b0, b1, (uint32_t *)d_tmp, stride, n_rows);
+    if (rc) return rc;
+    std::vector<uint64_t> tmp((size_t)n_rows * nb);
+    HIP_TRY(hipMemcpyAsync(tmp.data(), d_tmp, tmp.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    const uint32_t sh = (uint32_t)(site_begin & 63);
+    for (uint32_t i = 0; i < n_rows; ++i) {
+        const uint64_t *src = tmp.data() + (size_t)i * nb;
+        uint64_t *dst = out + (size_t)i * row_stride_words;
+        for (uint64_t w = 0; w < out_words; ++w) {
+            uint64_t v = src[w] >> sh;
+            if (sh && w + 1 < nb) v |= src[w + 1] << (64 - sh);
+            dst[w] = v;
+        }
+        if (W & 63) dst[out_words - 1] &= (~0ull) >> (64 - (W & 63));
+    }
+    return IMPOP_OK;
+}
+
+IMPOP_API int impop_matrix_info(const impop_matrix *m, uint32_t *n_hap, uint64_t *n_site, uint64_t *device_bytes,
+                                uint32_t *bytes_per_site) {
+    REQUIRE(m, "impop_matrix_info: matrix is NULL");
+    if (n_hap) *n_hap = m->g.n_hap;
+    if (n_site) *n_site = m->g.n_site;
+    if (device_bytes) *device_bytes = m->sb_bytes + m->hm_bytes;
+    if (bytes_per_site) *bytes_per_site = m->g.wps * 4;
+    return IMPOP_OK;
+}
+
+IMPOP_API int impop_matrix_free(impop_ctx *ctx, impop_matrix *m) {
+    if (!m) return IMPOP_OK;
+    if (ctx) {
+        hipSetDevice(ctx->device);
+        hipStreamSynchronize(ctx->stream);
+    }
+    if (m->d_sb) hipFree(m->d_sb);
+    if (m->d_hm) hipFree(m->d_hm);
+    delete m;
+    return IMPOP_OK;
+}

@@ -1,0 +1,326 @@
+// pairwise.hip — the all-pairs path: I_ij = sum_s b_is b_js for every haplotype pair of a
+// window, then the full pica2 / h-fst semantics (thresholds, rounding,
+// greedy grouping) on identities formed on the fly from the integer Gram matrix.
+//
+// v1 Gram kernel: 64x64 haplotype tile per 256-thread workgroup, upper-triangular tile grid,
+// hap-major rows staged through LDS in 32-dword (1024-site) K-chunks, 4x4 register tile per
+// thread with AND + v_bcnt accumulate.  Rows/cols are assigned with stride 16 so that the LDS
+// reads are conflict-free at row pitch 33 dwords.  This path is VALU-bound, not HBM-bound
+// (SURVEY.md §8d): its roof is the popcount issue rate, reported separately from the scan.
+#include <vector>
+
+#include "stats_kernels.h"
+
+namespace impop {
+
+constexpr int KC = 32;      // dwords per K-chunk
+constexpr int PITCH = 33;   // LDS row pitch (dwords)
+
+struct GramWindow {
+    uint64_t site_begin, site_end;
+};
+
+__global__ __launch_bounds__(256) void gram_kernel(const uint32_t *__restrict__ hm, uint64_t hm_stride, uint32_t n_tiles,
+                                                   const GramWindow *__restrict__ wins, int32_t *__restrict__ out,
+                                                   uint32_t ld, uint64_t out_stride) {
+    __shared__ uint32_t As[64 * PITCH];
+    __shared__ uint32_t Bs[64 * PITCH];
+    // decode upper-triangular tile pair (ti <= tj) from blockIdx.x
+    uint32_t rem = blockIdx.x, ti = 0;
+    while (rem >= n_tiles - ti) { rem -= n_tiles - ti; ++ti; }
+    const uint32_t tj = ti + rem;
+    const GramWindow w = wins[blockIdx.y];
+    const uint32_t tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
+    int32_t acc[4][4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[r][c] = 0;
+    if (w.site_end > w.site_begin) {
+        const uint64_t d0 = w.site_begin >> 5, d1 = (w.site_end + 31) >> 5;  // dword range
+        const uint32_t first_mask = 0xFFFFFFFFu << (w.site_begin & 31);
+        const uint32_t last_mask = (w.site_end & 31) ? (0xFFFFFFFFu >> (32 - (w.site_end & 31))) : 0xFFFFFFFFu;
+        const uint32_t *rowA = hm + (uint64_t)(ti * 64) * hm_stride;
+        const uint32_t *rowB = hm + (uint64_t)(tj * 64) * hm_stride;
+        for (uint64_t dk = d0; dk < d1; dk += KC) {
+            // stage 64 rows x KC dwords of both tiles (coalesced along the site axis)
+#pragma unroll
+            for (int i = 0; i < (64 * KC) / 256; ++i) {
+                const uint32_t e = tid + 256 * i, row = e / KC, col = e % KC;
+                const uint64_t d = dk + col;
+                uint32_t va = 0, vb = 0;
+                if (d < d1) {
+                    uint32_t m = 0xFFFFFFFFu;
+                    if (d == d0) m &= first_mask;
+                    if (d == d1 - 1) m &= last_mask;
+                    va = rowA[(uint64_t)row * hm_stride + d] & m;  // masking one operand suffices for AND
+                    vb = rowB[(uint64_t)row * hm_stride + d];
+                }
+                As[row * PITCH + col] = va;
+                Bs[row * PITCH + col] = vb;
+            }
+            __syncthreads();
+#pragma unroll 8
+            for (int k = 0; k < KC; ++k) {
+                uint32_t a[4], b[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) a[r] = As[(ty + 16 * r) * PITCH + k];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) b[c] = Bs[(tx + 16 * c) * PITCH + k];
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) acc[r][c] += __popc(a[r] & b[c]);
+            }
+            __syncthreads();
+        }
+    }
+    int32_t *o = out + (uint64_t)blockIdx.y * out_stride;
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            o[(uint64_t)(ti * 64 + ty + 16 * r) * ld + (tj * 64 + tx + 16 * c)] = acc[r][c];
+}
+
+// mirror the upper tiles into the lower triangle (only for host export)
+__global__ void gram_symmetrize_kernel(int32_t *g, uint32_t ld) {
+    const uint32_t i = blockIdx.y * blockDim.y + threadIdx.y, j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < ld && j < ld && (i / 64) > (j / 64)) g[(uint64_t)i * ld + j] = g[(uint64_t)j * ld + i];
+}
+
+__global__ void identity_dense_kernel(SimBatch b, uint32_t n, double *__restrict__ out) {
+    const uint32_t i = blockIdx.y * blockDim.y + threadIdx.y, j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n || j >= n) return;
+    const SimView S = sim_view(b, 0);
+    out[(uint64_t)i * n + j] = sim_get(S, i, j);
+}
+
+struct PairFinalIn {
+    const Pica2Out *pica;
+    const HfstOut *hfst;
+    const impop_window_stats *scan;  // integer S / W from the site scan of the same windows
+};
+__global__ void pairwise_finalize_kernel(PairFinalIn in, uint64_t n_windows, uint32_t nP, int d_pi_mode, int s_scope,
+                                         impop_pairwise_stats *__restrict__ out) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_windows) return;
+    const Pica2Out p = in.pica[i];
+    const HfstOut h = in.hfst[i];
+    const impop_window_stats s = in.scan[i];
+    impop_pairwise_stats r;
+    r.pi = p.pi; r.pi_site = p.pi_site;
+    r.fst = h.v[0]; r.pi_a = h.v[1]; r.pi_b = h.v[2]; r.pi_xy = h.v[3]; r.dxy = h.v[4]; r.da = h.v[5];
+    r.n_groups = p.n_groups; r.s_all = s.s_all; r.s_p = s.s_p; r.n_sites = s.n_sites; r.reserved = 0;
+    const double S = (double)(s_scope == 0 ? s.s_all : s.s_p);
+    const double pin = d_pi_mode == 0 ? py_round(p.pi_site, 8) : d_pi_mode == 1 ? p.pi_site : p.pi * (double)s.n_sites;
+    double D = __builtin_nan("");
+    if (nP >= 2 && pin == pin && pin >= 0) {
+        const TajConsts c = tajima_consts((int64_t)nP);
+        D = tajima_d_from(c, S, pin, nullptr, nullptr);
+    }
+    r.tajima_d = D;
+    out[i] = r;
+}
+
+static int launch_gram(impop_ctx *ctx, const impop_matrix *m, const GramWindow *d_wins, uint32_t n_win, int32_t *d_out) {
+    const uint32_t T = m->n_hap_pad / 64;
+    const uint32_t pairs = T * (T + 1) / 2;
+    REQUIRE(n_win <= 65535, "gram: at most 65535 windows per launch");
+    hipLaunchKernelGGL(gram_kernel, dim3(pairs, n_win), dim3(256), 0, ctx->stream, m->d_hm, m->hm_stride, T, d_wins, d_out,
+                       m->n_hap_pad, (uint64_t)m->n_hap_pad * m->n_hap_pad);
+    HIP_TRY(hipGetLastError());
+    return IMPOP_OK;
+}
+
+struct Carve2 {
+    char *base;
+    size_t off = 0;
+    explicit Carve2(void *p) : base((char *)p) {}
+    template <typename T>
+    T *take(size_t count) {
+        off = (off + 255) / 256 * 256;
+        T *p = reinterpret_cast<T *>(base + off);
+        off += count * sizeof(T);
+        return p;
+    }
+};
+
+}  // namespace impop
+
+using namespace impop;
+
+static int check_pairwise_args(impop_ctx *ctx, const impop_matrix *m, uint64_t s0, uint64_t s1, const char *fn) {
+    REQUIRE(ctx && m, "%s: NULL argument", fn);
+    REQUIRE(m->d_hm, "%s: matrix was created without IMPOP_KEEP_HAP_MAJOR", fn);
+    REQUIRE(s0 <= s1 && s1 <= m->g.n_site, "%s: bad site range [%llu,%llu)", fn, (unsigned long long)s0,
+            (unsigned long long)s1);
+    REQUIRE(s1 - s0 < (1ull << 31), "%s: window longer than 2^31 sites overflows int32 counts", fn);
+    return IMPOP_OK;
+}
+
+IMPOP_API int impop_pairwise_counts(impop_ctx *ctx, const impop_matrix *m, uint64_t site_begin, uint64_t site_end,
+                                    int32_t *out_host) {
+    int rc = check_pairwise_args(ctx, m, site_begin, site_end, "impop_pairwise_counts");
+    if (rc) return rc;
+    REQUIRE(out_host, "impop_pairwise_counts: out is NULL");
+    HIP_TRY(hipSetDevice(ctx->device));
+    const uint32_t n = m->g.n_hap, ld = m->n_hap_pad;
+    void *d = nullptr;
+    rc = ctx_scratch(ctx, 512 + (size_t)ld * ld * 4, &d);
+    if (rc) return rc;
+    Carve2 cv(d);
+    GramWindow *d_w = cv.take<GramWindow>(1);
+    int32_t *d_g = cv.take<int32_t>((size_t)ld * ld);
+    GramWindow w{site_begin, site_end};
+    HIP_TRY(hipMemcpyAsync(d_w, &w, sizeof w, hipMemcpyHostToDevice, ctx->stream));
+    rc = launch_gram(ctx, m, d_w, 1, d_g);
+    if (rc) return rc;
+    hipLaunchKernelGGL(gram_symmetrize_kernel, dim3((ld + 15) / 16, (ld + 15) / 16), dim3(16, 16), 0, ctx->stream, d_g, ld);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy2DAsync(out_host, (size_t)n * 4, d_g, (size_t)ld * 4, (size_t)n * 4, n, hipMemcpyDeviceToHost,
+                             ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return IMPOP_OK;
+}
+
+IMPOP_API int impop_pairwise_identity(impop_ctx *ctx, const impop_matrix *m, uint64_t site_begin, uint64_t site_end,
+                                      int identity_kind, double *out_host) {
+    int rc = check_pairwise_args(ctx, m, site_begin, site_end, "impop_pairwise_identity");
+    if (rc) return rc;
+    REQUIRE(out_host, "impop_pairwise_identity: out is NULL");
+    REQUIRE(identity_kind == IMPOP_IDENTITY_MATCH || identity_kind == IMPOP_IDENTITY_DICE,
+            "impop_pairwise_identity: unknown identity kind %d", identity_kind);
+    HIP_TRY(hipSetDevice(ctx->device));
+    const uint32_t n = m->g.n_hap, ld = m->n_hap_pad;
+    void *d = nullptr;
+    rc = ctx_scratch(ctx, 1024 + (size_t)ld * ld * 4 + (size_t)n * n * 8, &d);
+    if (rc) return rc;
+    Carve2 cv(d);
+    GramWindow *d_w = cv.take<GramWindow>(1);
+    uint64_t *d_W = cv.take<uint64_t>(1);
+    int32_t *d_g = cv.take<int32_t>((size_t)ld * ld);
+    double *d_id = cv.take<double>((size_t)n * n);
+    GramWindow w{site_begin, site_end};
+    const uint64_t W = site_end - site_begin;
+    HIP_TRY(hipMemcpyAsync(d_w, &w, sizeof w, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(d_W, &W, 8, hipMemcpyHostToDevice, ctx->stream));
+    rc = launch_gram(ctx, m, d_w, 1, d_g);
+    if (rc) return rc;
+    SimBatch b{};
+    b.gram = d_g; b.stride = (uint64_t)ld * ld; b.ld = ld; b.n = n; b.W = d_W; b.kind = identity_kind; b.round_digits = -1;
+    hipLaunchKernelGGL(identity_dense_kernel, dim3((n + 15) / 16, (n + 15) / 16), dim3(16, 16), 0, ctx->stream, b, n, d_id);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(out_host, d_id, (size_t)n * n * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return IMPOP_OK;
+}
+
+IMPOP_API int impop_pairwise_scan(impop_ctx *ctx, const impop_matrix *m, const impop_window *windows, uint64_t n_windows,
+                                  const uint64_t *mask_p, const uint64_t *mask_a, const uint64_t *mask_b,
+                                  const impop_pairwise_params *params, impop_pairwise_stats *out_host) {
+    REQUIRE(ctx && m && params, "impop_pairwise_scan: NULL argument");
+    REQUIRE(params->struct_size == sizeof(impop_pairwise_params), "impop_pairwise_params.struct_size mismatch");
+    REQUIRE(m->d_hm, "impop_pairwise_scan: matrix was created without IMPOP_KEEP_HAP_MAJOR");
+    REQUIRE(params->identity_kind == IMPOP_IDENTITY_MATCH || params->identity_kind == IMPOP_IDENTITY_DICE,
+            "impop_pairwise_scan: unknown identity kind");
+    REQUIRE(params->round_digits <= 19, "impop_pairwise_scan: round_digits > 19 unsupported");
+    REQUIRE(params->d_pi_mode >= 0 && params->d_pi_mode <= 2 && (params->s_scope == 0 || params->s_scope == 1),
+            "impop_pairwise_scan: bad d_pi_mode / s_scope");
+    if (!n_windows) return IMPOP_OK;
+    REQUIRE(windows && out_host, "impop_pairwise_scan: NULL windows/out");
+    for (uint64_t i = 0; i < n_windows; ++i) {
+        int rc = check_pairwise_args(ctx, m, windows[i].site_begin, windows[i].site_end, "impop_pairwise_scan");
+        if (rc) return rc;
+    }
+    HIP_TRY(hipSetDevice(ctx->device));
+    const uint32_t n = m->g.n_hap, ld = m->n_hap_pad;
+    // integer S / W of the same windows from the streaming scan
+    impop_scan_params sp;
+    sp.struct_size = sizeof sp; sp.d_pi_mode = params->d_pi_mode; sp.s_scope = params->s_scope; sp.tile_blocks = 0;
+    impop_scan_plan *plan = nullptr;
+    int rc = impop_scan_plan_create(ctx, m, windows, n_windows, mask_p, mask_a, mask_b, &sp, &plan);
+    if (rc) return rc;
+    auto fail = [&](int code) {
+        impop_scan_plan_destroy(plan);
+        return code;
+    };
+    // subset P index list and A/B flags
+    std::vector<uint32_t> idx;
+    std::vector<uint8_t> fa(n, 0), fb(n, 0);
+    for (uint32_t i = 0; i < n; ++i) {
+        const bool inP = mask_p ? ((mask_p[i >> 6] >> (i & 63)) & 1ull) : true;
+        if (inP) idx.push_back(i);
+        fa[i] = mask_a ? (uint8_t)((mask_a[i >> 6] >> (i & 63)) & 1ull) : 0;
+        fb[i] = mask_b ? (uint8_t)((mask_b[i >> 6] >> (i & 63)) & 1ull) : 0;
+    }
+    const uint32_t nP = (uint32_t)idx.size();
+    // windows are processed in chunks so the Gram scratch stays bounded (<= ~1 GiB)
+    const size_t gram_bytes = (size_t)ld * ld * 4;
+    uint64_t chunk = (1ull << 30) / gram_bytes;
+    if (chunk < 1) chunk = 1;
+    if (chunk > 4096) chunk = 4096;
+    if (chunk > n_windows) chunk = n_windows;
+    void *d = nullptr;
+    const size_t need = 4096 + chunk * (gram_bytes + sizeof(GramWindow) + 16 + sizeof(Pica2Out) + sizeof(HfstOut) +
+                                        sizeof(impop_window_stats) + sizeof(impop_pairwise_stats) + 2048) +
+                        (size_t)n * 8 + 4096;
+    rc = ctx_scratch(ctx, need, &d);
+    if (rc) return fail(rc);
+    Carve2 cv(d);
+    int32_t *d_g = cv.take<int32_t>(chunk * (size_t)ld * ld);
+    GramWindow *d_w = cv.take<GramWindow>(chunk);
+    uint64_t *d_W = cv.take<uint64_t>(chunk);
+    uint64_t *d_L = cv.take<uint64_t>(chunk);
+    Pica2Out *d_p = cv.take<Pica2Out>(chunk);
+    HfstOut *d_h = cv.take<HfstOut>(chunk);
+    impop_window_stats *d_s = cv.take<impop_window_stats>(chunk);
+    impop_pairwise_stats *d_o = cv.take<impop_pairwise_stats>(chunk);
+    uint32_t *d_idx = cv.take<uint32_t>(n ? n : 1);
+    uint8_t *d_fa = cv.take<uint8_t>(n ? n : 1);
+    uint8_t *d_fb = cv.take<uint8_t>(n ? n : 1);
+    hipError_t e;
+#define PW_TRY(expr) \
+    if ((e = (expr)) != hipSuccess) return fail(hip_fail(e, #expr, __FILE__, __LINE__))
+    if (nP) PW_TRY(hipMemcpyAsync(d_idx, idx.data(), (size_t)nP * 4, hipMemcpyHostToDevice, ctx->stream));
+    PW_TRY(hipMemcpyAsync(d_fa, fa.data(), n, hipMemcpyHostToDevice, ctx->stream));
+    PW_TRY(hipMemcpyAsync(d_fb, fb.data(), n, hipMemcpyHostToDevice, ctx->stream));
+    rc = impop_scan_plan_launch(plan, nullptr);
+    if (rc) return fail(rc);
+    std::vector<impop_window_stats> scan_host(n_windows);
+    rc = impop_scan_plan_fetch(plan, scan_host.data());
+    if (rc) return fail(rc);
+    std::vector<GramWindow> gw(chunk);
+    std::vector<uint64_t> Wv(chunk), Lv(chunk);
+    for (uint64_t base = 0; base < n_windows; base += chunk) {
+        const uint64_t cnt = std::min<uint64_t>(chunk, n_windows - base);
+        for (uint64_t k = 0; k < cnt; ++k) {
+            gw[k] = {windows[base + k].site_begin, windows[base + k].site_end};
+            Wv[k] = windows[base + k].site_end - windows[base + k].site_begin;
+            Lv[k] = windows[base + k].seq_len;
+        }
+        PW_TRY(hipMemcpyAsync(d_w, gw.data(), cnt * sizeof(GramWindow), hipMemcpyHostToDevice, ctx->stream));
+        PW_TRY(hipMemcpyAsync(d_W, Wv.data(), cnt * 8, hipMemcpyHostToDevice, ctx->stream));
+        PW_TRY(hipMemcpyAsync(d_L, Lv.data(), cnt * 8, hipMemcpyHostToDevice, ctx->stream));
+        PW_TRY(hipMemcpyAsync(d_s, scan_host.data() + base, cnt * sizeof(impop_window_stats), hipMemcpyHostToDevice,
+                              ctx->stream));
+        rc = launch_gram(ctx, m, d_w, (uint32_t)cnt, d_g);
+        if (rc) return fail(rc);
+        SimBatch b{};
+        b.gram = d_g; b.stride = (uint64_t)ld * ld; b.ld = ld; b.n = n; b.W = d_W; b.kind = params->identity_kind;
+        b.round_digits = params->round_digits < 0 ? -1 : params->round_digits;
+        rc = launch_pica2(ctx, b, cnt, mask_p ? d_idx : nullptr, nP, params->threshold, d_L, d_p, nullptr);
+        if (rc) return fail(rc);
+        rc = launch_hfst(ctx, b, cnt, d_fa, d_fb, d_L, d_h);
+        if (rc) return fail(rc);
+        PairFinalIn in{d_p, d_h, d_s};
+        hipLaunchKernelGGL(pairwise_finalize_kernel, dim3((uint32_t)((cnt + 63) / 64)), dim3(64), 0, ctx->stream, in, cnt,
+                           nP, params->d_pi_mode, params->s_scope, d_o);
+        PW_TRY(hipGetLastError());
+        PW_TRY(hipMemcpyAsync(out_host + base, d_o, cnt * sizeof(impop_pairwise_stats), hipMemcpyDeviceToHost, ctx->stream));
+        PW_TRY(hipStreamSynchronize(ctx->stream));  // gw/Wv/Lv are reused by the next chunk
+    }
+#undef PW_TRY
+    impop_scan_plan_destroy(plan);
+    return IMPOP_OK;
+}

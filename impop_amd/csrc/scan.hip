@@ -1,0 +1,583 @@
+// scan.hip — the HBM-bound hot path: one streaming pass over the SB64 presence matrix gives,
+// per window, S, sum c(n-c) for the subset P and populations A, B, the A x B cross sum, and
+// from those pi, Hudson Fst and Tajima's D.
+//
+// Work decomposition: windows -> elementary segments (so overlapping / sliding windows read
+// every site once) -> tiles of <= tile_blocks 64-site blocks.  One 256-thread workgroup per
+// tile; wave w takes blocks b0+w, b0+w+4, ...; lane l of a wave owns site 64b+l and pulls its
+// wps dwords with ceil(wps/4) fully coalesced 1 KiB wave loads (layout: internal.h).  The
+// three population masks are wave-uniform and live in SGPRs.  Integer partials per tile are
+// written once (no atomics => deterministic); a second tiny kernel sums each window's tiles
+// and evaluates the fp64 statistics in the reference's operation order.
+#include <algorithm>
+#include <map>
+#include <vector>
+
+#include "device_utils.h"
+#include "internal.h"
+
+namespace impop {
+
+struct ScanTile {
+    uint64_t site_begin, site_end;
+};
+struct TilePartial {  // 48 B
+    uint32_t s_all, s_p, s_a, s_b;
+    uint64_t sum_p, sum_a, sum_b, sum_ab;
+};
+struct WinDesc {
+    uint64_t t0, t1;  // tile range
+    uint64_t n_sites;
+    uint64_t seq_len;
+};
+struct PopSizes {
+    uint32_t n, nP, nA, nB;
+};
+
+template <int WPS>
+struct MaskArgs {
+    uint32_t p[WPS], a[WPS], b[WPS];
+};
+
+struct u32x3 {
+    uint32_t x, y, z;
+};
+
+template <int WPS>
+__device__ __forceinline__ void load_site(const uint32_t *__restrict__ blk, uint32_t lane, uint32_t (&w)[WPS]) {
+    constexpr int G = (WPS + 3) / 4;
+    constexpr int R = WPS - 4 * (G - 1);
+#pragma unroll
+    for (int g = 0; g < G - 1; ++g) {
+        const uint4 v = *reinterpret_cast<const uint4 *>(blk + g * 256 + lane * 4);
+        w[4 * g + 0] = v.x; w[4 * g + 1] = v.y; w[4 * g + 2] = v.z; w[4 * g + 3] = v.w;
+    }
+    const uint32_t *last = blk + (G - 1) * 256 + lane * R;
+    if constexpr (R == 4) {
+        const uint4 v = *reinterpret_cast<const uint4 *>(last);
+        w[4 * (G - 1) + 0] = v.x; w[4 * (G - 1) + 1] = v.y; w[4 * (G - 1) + 2] = v.z; w[4 * (G - 1) + 3] = v.w;
+    } else if constexpr (R == 3) {
+        const u32x3 v = *reinterpret_cast<const u32x3 *>(last);
+        w[4 * (G - 1) + 0] = v.x; w[4 * (G - 1) + 1] = v.y; w[4 * (G - 1) + 2] = v.z;
+    } else if constexpr (R == 2) {
+        const uint2 v = *reinterpret_cast<const uint2 *>(last);
+        w[4 * (G - 1) + 0] = v.x; w[4 * (G - 1) + 1] = v.y;
+    } else {
+        w[4 * (G - 1)] = *last;
+    }
+}
+
+struct LaneAcc {
+    uint32_t s_all = 0, s_p = 0, s_a = 0, s_b = 0;
+    uint64_t q_p = 0, q_a = 0, q_b = 0, q_ab = 0;
+};
+
+template <int WPS, bool SUBSET_P>
+__device__ __forceinline__ void site_accumulate(const uint32_t (&w)[WPS], const MaskArgs<WPS> &mk, const PopSizes &ps,
+                                                bool valid, LaneAcc &acc) {
+    uint32_t c = 0, cP = 0, cA = 0, cB = 0;
+#pragma unroll
+    for (int k = 0; k < WPS; ++k) {
+        c += __popc(w[k]);
+        if (SUBSET_P) cP += __popc(w[k] & mk.p[k]);
+        cA += __popc(w[k] & mk.a[k]);
+        cB += __popc(w[k] & mk.b[k]);
+    }
+    if (!SUBSET_P) cP = c;
+    if (valid) {
+        acc.s_all += (c != 0 && c != ps.n);
+        acc.s_p += (cP != 0 && cP != ps.nP);
+        acc.s_a += (cA != 0 && cA != ps.nA);
+        acc.s_b += (cB != 0 && cB != ps.nB);
+        acc.q_p += cP * (ps.nP - cP);
+        acc.q_a += cA * (ps.nA - cA);
+        acc.q_b += cB * (ps.nB - cB);
+        acc.q_ab += cA * (ps.nB - cB) + cB * (ps.nA - cA);
+    }
+}
+
+__device__ __forceinline__ void tile_reduce_store(LaneAcc &acc, TilePartial *out) {
+    __shared__ uint64_t red[4][8];
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t s0 = wave_sum_u32(acc.s_all), s1 = wave_sum_u32(acc.s_p), s2 = wave_sum_u32(acc.s_a),
+                   s3 = wave_sum_u32(acc.s_b);
+    const uint64_t q0 = wave_sum_u64(acc.q_p), q1 = wave_sum_u64(acc.q_a), q2 = wave_sum_u64(acc.q_b),
+                   q3 = wave_sum_u64(acc.q_ab);
+    if (lane == 0) {
+        red[wave][0] = s0; red[wave][1] = s1; red[wave][2] = s2; red[wave][3] = s3;
+        red[wave][4] = q0; red[wave][5] = q1; red[wave][6] = q2; red[wave][7] = q3;
+    }
+    __syncthreads();
+    if (threadIdx.x < 8) {
+        const uint64_t v = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+        TilePartial *o = out + blockIdx.x;
+        switch (threadIdx.x) {
+            case 0: o->s_all = (uint32_t)v; break;
+            case 1: o->s_p = (uint32_t)v; break;
+            case 2: o->s_a = (uint32_t)v; break;
+            case 3: o->s_b = (uint32_t)v; break;
+            case 4: o->sum_p = v; break;
+            case 5: o->sum_a = v; break;
+            case 6: o->sum_b = v; break;
+            default: o->sum_ab = v; break;
+        }
+    }
+}
+
+template <int WPS, bool SUBSET_P>
+__global__ __launch_bounds__(256) void scan_tiles_kernel(const uint32_t *__restrict__ sb,
+                                                         const ScanTile *__restrict__ tiles, const MaskArgs<WPS> mk,
+                                                         const PopSizes ps, TilePartial *__restrict__ out) {
+    const ScanTile t = tiles[blockIdx.x];
+    const uint64_t b0 = t.site_begin >> 6, b1 = (t.site_end + 63) >> 6;
+    // wave index through readfirstlane: block addresses and the loop stay scalar (SGPR) state
+    const uint32_t lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    LaneAcc acc;
+    uint64_t b = b0 + wave;
+    // two blocks per iteration: 2*ceil(WPS/4) independent 1 KiB wave loads in flight per wave
+    for (; b + 4 < b1; b += 8) {
+        uint32_t w0[WPS], w1[WPS];
+        load_site<WPS>(sb + b * (64ull * WPS), lane, w0);
+        load_site<WPS>(sb + (b + 4) * (64ull * WPS), lane, w1);
+        const uint64_t s0 = b * 64 + lane, s1 = (b + 4) * 64 + lane;
+        site_accumulate<WPS, SUBSET_P>(w0, mk, ps, s0 >= t.site_begin && s0 < t.site_end, acc);
+        site_accumulate<WPS, SUBSET_P>(w1, mk, ps, s1 >= t.site_begin && s1 < t.site_end, acc);
+    }
+    if (b < b1) {
+        uint32_t w0[WPS];
+        load_site<WPS>(sb + b * (64ull * WPS), lane, w0);
+        const uint64_t s0 = b * 64 + lane;
+        site_accumulate<WPS, SUBSET_P>(w0, mk, ps, s0 >= t.site_begin && s0 < t.site_end, acc);
+    }
+    tile_reduce_store(acc, out);
+}
+
+// any wps: masks come from memory (scalar loads), dwords are streamed granule by granule
+__global__ __launch_bounds__(256) void scan_tiles_generic_kernel(const uint32_t *__restrict__ sb,
+                                                                 const ScanTile *__restrict__ tiles,
+                                                                 const uint32_t *__restrict__ masks, uint32_t wps,
+                                                                 uint32_t G, uint32_t r, const PopSizes ps,
+                                                                 TilePartial *__restrict__ out) {
+    const ScanTile t = tiles[blockIdx.x];
+    const uint64_t b0 = t.site_begin >> 6, b1 = (t.site_end + 63) >> 6;
+    const uint32_t lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t *mp = masks, *ma = masks + wps, *mb = masks + 2 * wps;
+    LaneAcc acc;
+    for (uint64_t b = b0 + wave; b < b1; b += 4) {
+        const uint32_t *blk = sb + b * 64ull * wps;
+        uint32_t c = 0, cP = 0, cA = 0, cB = 0;
+#pragma unroll 4
+        for (uint32_t g = 0; g + 1 < G; ++g) {
+            const uint4 v = *reinterpret_cast<const uint4 *>(blk + (uint64_t)g * 256 + lane * 4);
+            const uint32_t k = 4 * g;
+            c += __popc(v.x) + __popc(v.y) + __popc(v.z) + __popc(v.w);
+            cP += __popc(v.x & mp[k]) + __popc(v.y & mp[k + 1]) + __popc(v.z & mp[k + 2]) + __popc(v.w & mp[k + 3]);
+            cA += __popc(v.x & ma[k]) + __popc(v.y & ma[k + 1]) + __popc(v.z & ma[k + 2]) + __popc(v.w & ma[k + 3]);
+            cB += __popc(v.x & mb[k]) + __popc(v.y & mb[k + 1]) + __popc(v.z & mb[k + 2]) + __popc(v.w & mb[k + 3]);
+        }
+        const uint32_t *last = blk + (uint64_t)(G - 1) * 256 + lane * r;
+        for (uint32_t j = 0; j < r; ++j) {
+            const uint32_t v = last[j], k = 4 * (G - 1) + j;
+            c += __popc(v); cP += __popc(v & mp[k]); cA += __popc(v & ma[k]); cB += __popc(v & mb[k]);
+        }
+        const uint64_t s = b * 64 + lane;
+        if (s >= t.site_begin && s < t.site_end) {
+            acc.s_all += (c != 0 && c != ps.n);
+            acc.s_p += (cP != 0 && cP != ps.nP);
+            acc.s_a += (cA != 0 && cA != ps.nA);
+            acc.s_b += (cB != 0 && cB != ps.nB);
+            acc.q_p += cP * (ps.nP - cP);
+            acc.q_a += cA * (ps.nA - cA);
+            acc.q_b += cB * (ps.nB - cB);
+            acc.q_ab += cA * (ps.nB - cB) + cB * (ps.nA - cA);
+        }
+    }
+    tile_reduce_store(acc, out);
+}
+
+// One thread per window: integer totals, then the fp64 epilogue.  Same operation order as
+// oracle_window_sitecount (oracle/impop_oracle.c) which restates pica2.py:154,164,
+// h-fst.py:203-240 and tj_d.py:53-65 on the exact pair sums.
+__global__ void scan_finalize_kernel(const TilePartial *__restrict__ parts, const WinDesc *__restrict__ wins,
+                                     uint64_t n_windows, PopSizes ps, const double *__restrict__ taj, int d_pi_mode,
+                                     int s_scope, impop_window_stats *__restrict__ out) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_windows) return;
+    const WinDesc w = wins[i];
+    uint32_t s_all = 0, s_p = 0, s_a = 0, s_b = 0;
+    uint64_t sum_p = 0, sum_a = 0, sum_b = 0, sum_ab = 0;
+    for (uint64_t t = w.t0; t < w.t1; ++t) {
+        const TilePartial p = parts[t];
+        s_all += p.s_all; s_p += p.s_p; s_a += p.s_a; s_b += p.s_b;
+        sum_p += p.sum_p; sum_a += p.sum_a; sum_b += p.sum_b; sum_ab += p.sum_ab;
+    }
+    impop_window_stats r;
+    r.n_sites = (uint32_t)w.n_sites;
+    r.s_all = s_all; r.s_p = s_p; r.s_a = s_a; r.s_b = s_b; r.flags = 0;
+    r.sum_p = sum_p; r.sum_a = sum_a; r.sum_b = sum_b; r.sum_ab = sum_ab;
+    const double nan = __builtin_nan("");
+    const double W = (double)w.n_sites;
+    const double seq_len = (double)w.seq_len;
+    const double nP = (double)ps.nP, nA = (double)ps.nA, nB = (double)ps.nB;
+    const double pairsP = nP * (double)(ps.nP - 1) / 2.0;
+    const double pi = (ps.nP >= 2 && W > 0) ? (double)sum_p / (pairsP * W) : 0.0;
+    const double pi_site = (seq_len != 0.0) ? pi / seq_len : nan;
+    const double pairsA = nA * (nA - 1.0) / 2.0, pairsB = nB * (nB - 1.0) / 2.0;
+    double pi_a = (ps.nA >= 2 && W > 0) ? (double)sum_a / (pairsA * W) : 0.0;
+    double pi_b = (ps.nB >= 2 && W > 0) ? (double)sum_b / (pairsB * W) : 0.0;
+    double dxy = (ps.nA && ps.nB && W > 0) ? (double)sum_ab / (nA * nB * W) : 0.0;
+    double pi_xy = 0.5 * (pi_a + pi_b);
+    const double fst = (dxy > 0) ? (dxy - pi_xy) / dxy : 0.0;
+    double da = dxy - pi_xy;
+    if (seq_len > 0) {
+        pi_a /= seq_len; pi_b /= seq_len; da = (dxy - pi_xy) / seq_len; pi_xy /= seq_len; dxy /= seq_len;
+    }
+    r.pi = pi; r.pi_site = pi_site; r.pi_a = pi_a; r.pi_b = pi_b; r.pi_xy = pi_xy; r.dxy = dxy; r.da = da; r.fst = fst;
+    const double S = (double)(s_scope == 0 ? s_all : s_p);
+    const double pin = d_pi_mode == 0 ? py_round(pi_site, 8) : d_pi_mode == 1 ? pi_site : pi * W;
+    double D = nan;
+    if (ps.nP >= 2 && pin == pin) {
+        TajConsts c;
+        c.a1 = taj[0]; c.a2 = taj[1]; c.b1 = taj[2]; c.b2 = taj[3]; c.c1 = taj[4]; c.c2 = taj[5]; c.e1 = taj[6]; c.e2 = taj[7];
+        D = tajima_d_from(c, S, pin, nullptr, nullptr);
+    }
+    r.tajima_d = D;
+    out[i] = r;
+}
+
+__global__ __launch_bounds__(256) void site_counts_kernel(const uint32_t *__restrict__ sb, const uint32_t *__restrict__ mask,
+                                                          uint32_t wps, uint32_t G, uint32_t r, uint64_t site_begin,
+                                                          uint64_t site_end, uint32_t *__restrict__ out) {
+    const uint32_t lane = threadIdx.x & 63;
+    const uint64_t b = (site_begin >> 6) + (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const uint64_t s = b * 64 + lane;
+    if (s < site_begin || s >= site_end) return;
+    const uint32_t *blk = sb + b * 64ull * wps;
+    uint32_t c = 0;
+    for (uint32_t k = 0; k < wps; ++k) {
+        const uint32_t g = k >> 2;
+        const uint32_t v = (g + 1 < G) ? blk[(uint64_t)g * 256 + lane * 4 + (k & 3)]
+                                       : blk[(uint64_t)(G - 1) * 256 + lane * r + (k - 4 * (G - 1))];
+        c += __popc(v & mask[k]);
+    }
+    out[s - site_begin] = c;
+}
+
+// mask bitset (uint64 words, n bits) -> wps dwords clipped to n; NULL -> `fill`
+static void mask_to_dwords(const uint64_t *mask, uint32_t n, uint32_t wps, bool fill_all, std::vector<uint32_t> &out) {
+    out.assign(wps, 0u);
+    for (uint32_t k = 0; k < wps; ++k) {
+        uint32_t v;
+        if (mask) v = (uint32_t)(mask[k >> 1] >> (32 * (k & 1)));
+        else v = fill_all ? 0xFFFFFFFFu : 0u;
+        const uint32_t lo = 32 * k;
+        if (lo + 32 > n) v &= (n > lo) ? (uint32_t)((1ull << (n - lo)) - 1ull) : 0u;
+        out[k] = v;
+    }
+}
+static uint32_t popcount_vec(const std::vector<uint32_t> &v) {
+    uint32_t c = 0;
+    for (uint32_t x : v) c += (uint32_t)__builtin_popcount(x);
+    return c;
+}
+
+}  // namespace impop
+
+using namespace impop;
+
+struct impop_scan_plan {
+    impop_ctx *ctx = nullptr;
+    const impop_matrix *m = nullptr;
+    uint64_t n_windows = 0, n_tiles = 0, bytes_streamed = 0;
+    PopSizes ps{};
+    bool subset_p = false;
+    std::vector<uint32_t> masks;  // p | a | b, wps dwords each
+    int d_pi_mode = 0, s_scope = 0;
+    ScanTile *d_tiles = nullptr;
+    WinDesc *d_wins = nullptr;
+    TilePartial *d_parts = nullptr;
+    uint32_t *d_masks = nullptr;
+    impop_window_stats *d_out = nullptr;
+    bool timing = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> events;  // pool, one pair per timed launch
+    size_t events_used = 0;
+};
+
+template <int WPS>
+static void launch_scan_fixed(impop_scan_plan *p, hipStream_t st) {
+    MaskArgs<WPS> mk;
+    for (int k = 0; k < WPS; ++k) {
+        mk.p[k] = p->masks[k];
+        mk.a[k] = p->masks[WPS + k];
+        mk.b[k] = p->masks[2 * WPS + k];
+    }
+    if (p->subset_p)
+        hipLaunchKernelGGL((scan_tiles_kernel<WPS, true>), dim3((uint32_t)p->n_tiles), dim3(256), 0, st, p->m->d_sb,
+                           p->d_tiles, mk, p->ps, p->d_parts);
+    else
+        hipLaunchKernelGGL((scan_tiles_kernel<WPS, false>), dim3((uint32_t)p->n_tiles), dim3(256), 0, st, p->m->d_sb,
+                           p->d_tiles, mk, p->ps, p->d_parts);
+}
+
+IMPOP_API int impop_scan_plan_create(impop_ctx *ctx, const impop_matrix *m, const impop_window *windows,
+                                     uint64_t n_windows, const uint64_t *mask_p, const uint64_t *mask_a,
+                                     const uint64_t *mask_b, const impop_scan_params *params, impop_scan_plan **out) {
+    REQUIRE(ctx && m && out, "impop_scan_plan_create: NULL argument");
+    *out = nullptr;
+    REQUIRE(n_windows == 0 || windows, "impop_scan_plan_create: windows is NULL");
+    REQUIRE(m->device == ctx->device, "impop_scan_plan_create: matrix lives on device %d, context on %d", m->device,
+            ctx->device);
+    REQUIRE(m->g.n_hap <= 65535, "impop_scan: n_hap %u > 65535 not supported by the 32-bit per-site products",
+            m->g.n_hap);
+    impop_scan_params prm;
+    prm.struct_size = sizeof prm; prm.d_pi_mode = 0; prm.s_scope = 0; prm.tile_blocks = 0;
+    if (params) {
+        REQUIRE(params->struct_size == sizeof prm, "impop_scan_params.struct_size %u != %zu", params->struct_size, sizeof prm);
+        prm = *params;
+    }
+    REQUIRE(prm.d_pi_mode >= 0 && prm.d_pi_mode <= 2, "impop_scan_params.d_pi_mode must be 0..2");
+    REQUIRE(prm.s_scope == 0 || prm.s_scope == 1, "impop_scan_params.s_scope must be 0 or 1");
+    const uint32_t tile_blocks = prm.tile_blocks ? prm.tile_blocks : 64;
+    REQUIRE(tile_blocks <= 4096, "impop_scan_params.tile_blocks too large");
+    for (uint64_t i = 0; i < n_windows; ++i) {
+        REQUIRE(windows[i].site_begin <= windows[i].site_end && windows[i].site_end <= m->g.n_site,
+                "window %llu: bad site range [%llu,%llu) for %llu sites", (unsigned long long)i,
+                (unsigned long long)windows[i].site_begin, (unsigned long long)windows[i].site_end,
+                (unsigned long long)m->g.n_site);
+        REQUIRE(windows[i].site_end - windows[i].site_begin <= 0xFFFFFFFFull, "window %llu longer than 2^32 sites",
+                (unsigned long long)i);
+    }
+    HIP_TRY(hipSetDevice(ctx->device));
+    impop_scan_plan *p = new impop_scan_plan();
+    p->ctx = ctx; p->m = m; p->n_windows = n_windows;
+    p->d_pi_mode = prm.d_pi_mode; p->s_scope = prm.s_scope;
+    const uint32_t n = m->g.n_hap, wps = m->g.wps;
+    // masks; overlap of A and B is removed from both (h-fst.py:181-185)
+    std::vector<uint32_t> mp, ma, mb;
+    mask_to_dwords(mask_p, n, wps, true, mp);
+    mask_to_dwords(mask_a, n, wps, false, ma);
+    mask_to_dwords(mask_b, n, wps, false, mb);
+    for (uint32_t k = 0; k < wps; ++k) {
+        const uint32_t ov = ma[k] & mb[k];
+        ma[k] &= ~ov; mb[k] &= ~ov;
+    }
+    p->ps.n = n; p->ps.nP = popcount_vec(mp); p->ps.nA = popcount_vec(ma); p->ps.nB = popcount_vec(mb);
+    p->subset_p = p->ps.nP != n;
+    p->masks.reserve(3 * wps);
+    p->masks.insert(p->masks.end(), mp.begin(), mp.end());
+    p->masks.insert(p->masks.end(), ma.begin(), ma.end());
+    p->masks.insert(p->masks.end(), mb.begin(), mb.end());
+
+    // elementary segments between sorted window boundaries; a segment is tiled iff some window covers it
+    std::vector<uint64_t> cuts;
+    cuts.reserve(2 * n_windows);
+    for (uint64_t i = 0; i < n_windows; ++i)
+        if (windows[i].site_end > windows[i].site_begin) {
+            cuts.push_back(windows[i].site_begin);
+            cuts.push_back(windows[i].site_end);
+        }
+    std::sort(cuts.begin(), cuts.end());
+    cuts.erase(std::unique(cuts.begin(), cuts.end()), cuts.end());
+    std::vector<int64_t> cover(cuts.size() + 1, 0);
+    auto cut_index = [&](uint64_t s) { return (size_t)(std::lower_bound(cuts.begin(), cuts.end(), s) - cuts.begin()); };
+    for (uint64_t i = 0; i < n_windows; ++i)
+        if (windows[i].site_end > windows[i].site_begin) {
+            cover[cut_index(windows[i].site_begin)] += 1;
+            cover[cut_index(windows[i].site_end)] -= 1;
+        }
+    std::vector<ScanTile> tiles;
+    std::vector<uint64_t> seg_tile_start(cuts.size() + 1, 0);
+    int64_t depth = 0;
+    const uint64_t tile_sites = (uint64_t)tile_blocks * 64;
+    for (size_t k = 0; k + 1 < cuts.size(); ++k) {
+        seg_tile_start[k] = tiles.size();
+        depth += cover[k];
+        if (depth <= 0) continue;
+        // tiles are cut on 64-site block boundaries of the matrix so interior tiles read whole blocks
+        uint64_t s = cuts[k];
+        const uint64_t e = cuts[k + 1];
+        while (s < e) {
+            uint64_t t_end = ((s / 64) + tile_blocks) * 64;  // block-aligned end
+            if (t_end > e) t_end = e;
+            tiles.push_back({s, t_end});
+            p->bytes_streamed += ((t_end + 63) / 64 - s / 64) * 64ull * wps * 4ull;
+            s = t_end;
+        }
+    }
+    (void)tile_sites;
+    if (!cuts.empty()) seg_tile_start[cuts.size() - 1] = tiles.size();
+    seg_tile_start[cuts.size()] = tiles.size();
+    std::vector<WinDesc> wd(n_windows);
+    for (uint64_t i = 0; i < n_windows; ++i) {
+        WinDesc &w = wd[i];
+        w.n_sites = windows[i].site_end - windows[i].site_begin;
+        w.seq_len = windows[i].seq_len;
+        if (w.n_sites) {
+            w.t0 = seg_tile_start[cut_index(windows[i].site_begin)];
+            w.t1 = seg_tile_start[cut_index(windows[i].site_end)];
+        } else {
+            w.t0 = w.t1 = 0;
+        }
+    }
+    p->n_tiles = tiles.size();
+    auto fail = [&](int code) {
+        impop_scan_plan_destroy(p);
+        return code;
+    };
+    if (p->n_tiles >= 0x7FFFFFFFull) {
+        set_error("impop_scan: %llu tiles exceed one launch; raise tile_blocks", (unsigned long long)p->n_tiles);
+        return fail(IMPOP_E_INVALID);
+    }
+    hipError_t e;
+#define PLAN_TRY(expr) \
+    if ((e = (expr)) != hipSuccess) return fail(hip_fail(e, #expr, __FILE__, __LINE__))
+    PLAN_TRY(hipMalloc((void **)&p->d_tiles, std::max<size_t>(tiles.size(), 1) * sizeof(ScanTile)));
+    PLAN_TRY(hipMalloc((void **)&p->d_parts, std::max<size_t>(tiles.size(), 1) * sizeof(TilePartial)));
+    PLAN_TRY(hipMalloc((void **)&p->d_wins, std::max<size_t>(n_windows, 1) * sizeof(WinDesc)));
+    PLAN_TRY(hipMalloc((void **)&p->d_out, std::max<size_t>(n_windows, 1) * sizeof(impop_window_stats)));
+    PLAN_TRY(hipMalloc((void **)&p->d_masks, (size_t)3 * wps * 4));
+    if (!tiles.empty()) PLAN_TRY(hipMemcpyAsync(p->d_tiles, tiles.data(), tiles.size() * sizeof(ScanTile), hipMemcpyHostToDevice, ctx->stream));
+    if (n_windows) PLAN_TRY(hipMemcpyAsync(p->d_wins, wd.data(), wd.size() * sizeof(WinDesc), hipMemcpyHostToDevice, ctx->stream));
+    PLAN_TRY(hipMemcpyAsync(p->d_masks, p->masks.data(), (size_t)3 * wps * 4, hipMemcpyHostToDevice, ctx->stream));
+    PLAN_TRY(hipStreamSynchronize(ctx->stream));  // host vectors die at return
+#undef PLAN_TRY
+    int rc = ensure_tajima_consts(ctx, p->ps.nP >= 2 ? (int64_t)p->ps.nP : 2);
+    if (rc) return fail(rc);
+    *out = p;
+    return IMPOP_OK;
+}
+
+IMPOP_API int impop_scan_plan_launch(impop_scan_plan *p, void *d_out) {
+    REQUIRE(p, "impop_scan_plan_launch: plan is NULL");
+    impop_ctx *ctx = p->ctx;
+    hipStream_t st = ctx->stream;
+    // the cached Tajima constants belong to the context; another plan may have changed n since
+    int rc = ensure_tajima_consts(ctx, p->ps.nP >= 2 ? (int64_t)p->ps.nP : 2);
+    if (rc) return rc;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    if (p->timing && p->n_tiles) {
+        if (p->events_used == p->events.size()) {
+            hipEvent_t a, b;
+            HIP_TRY(hipEventCreate(&a));
+            HIP_TRY(hipEventCreate(&b));
+            p->events.push_back({a, b});
+        }
+        ev0 = p->events[p->events_used].first;
+        ev1 = p->events[p->events_used].second;
+        p->events_used++;
+        HIP_TRY(hipEventRecord(ev0, st));
+    }
+    if (p->n_tiles) {
+        switch (p->m->g.wps) {
+#define CASE(W) case W: launch_scan_fixed<W>(p, st); break;
+            CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8)
+            CASE(9) CASE(10) CASE(11) CASE(12) CASE(13) CASE(14) CASE(15) CASE(16)
+#undef CASE
+            default:
+                hipLaunchKernelGGL(scan_tiles_generic_kernel, dim3((uint32_t)p->n_tiles), dim3(256), 0, st, p->m->d_sb,
+                                   p->d_tiles, p->d_masks, p->m->g.wps, p->m->g.G, p->m->g.r, p->ps, p->d_parts);
+        }
+        HIP_TRY(hipGetLastError());
+        if (ev1) HIP_TRY(hipEventRecord(ev1, st));
+    }
+    if (p->n_windows) {
+        impop_window_stats *dst = d_out ? (impop_window_stats *)d_out : p->d_out;
+        hipLaunchKernelGGL(scan_finalize_kernel, dim3((uint32_t)((p->n_windows + 127) / 128)), dim3(128), 0, st, p->d_parts,
+                           p->d_wins, p->n_windows, p->ps, ctx->d_taj, p->d_pi_mode, p->s_scope, dst);
+        HIP_TRY(hipGetLastError());
+    }
+    return IMPOP_OK;
+}
+
+IMPOP_API int impop_scan_plan_fetch(impop_scan_plan *p, impop_window_stats *out_host) {
+    REQUIRE(p && (out_host || p->n_windows == 0), "impop_scan_plan_fetch: NULL argument");
+    if (p->n_windows)
+        HIP_TRY(hipMemcpyAsync(out_host, p->d_out, p->n_windows * sizeof(impop_window_stats), hipMemcpyDeviceToHost,
+                               p->ctx->stream));
+    HIP_TRY(hipStreamSynchronize(p->ctx->stream));
+    return IMPOP_OK;
+}
+
+IMPOP_API int impop_scan_plan_info(const impop_scan_plan *p, uint64_t *n_tiles, uint64_t *bytes_streamed) {
+    REQUIRE(p, "impop_scan_plan_info: plan is NULL");
+    if (n_tiles) *n_tiles = p->n_tiles;
+    if (bytes_streamed) *bytes_streamed = p->bytes_streamed;
+    return IMPOP_OK;
+}
+
+IMPOP_API int impop_scan_plan_timing(impop_scan_plan *p, int enable) {
+    REQUIRE(p, "impop_scan_plan_timing: plan is NULL");
+    HIP_TRY(hipStreamSynchronize(p->ctx->stream));
+    p->timing = enable != 0;
+    p->events_used = 0;
+    return IMPOP_OK;
+}
+
+IMPOP_API int impop_scan_plan_elapsed(impop_scan_plan *p, double *total_ms, uint64_t *launches) {
+    REQUIRE(p, "impop_scan_plan_elapsed: plan is NULL");
+    HIP_TRY(hipStreamSynchronize(p->ctx->stream));
+    double t = 0.0;
+    for (size_t i = 0; i < p->events_used; ++i) {
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, p->events[i].first, p->events[i].second));
+        t += (double)ms;
+    }
+    if (total_ms) *total_ms = t;
+    if (launches) *launches = p->events_used;
+    return IMPOP_OK;
+}
+
+IMPOP_API int impop_scan_plan_destroy(impop_scan_plan *p) {
+    if (!p) return IMPOP_OK;
+    hipSetDevice(p->ctx->device);
+    hipStreamSynchronize(p->ctx->stream);
+    for (auto &e : p->events) {
+        hipEventDestroy(e.first);
+        hipEventDestroy(e.second);
+    }
+    if (p->d_tiles) hipFree(p->d_tiles);
+    if (p->d_parts) hipFree(p->d_parts);
+    if (p->d_wins) hipFree(p->d_wins);
+    if (p->d_out) hipFree(p->d_out);
+    if (p->d_masks) hipFree(p->d_masks);
+    delete p;
+    return IMPOP_OK;
+}
+
+IMPOP_API int impop_scan(impop_ctx *ctx, const impop_matrix *m, const impop_window *windows, uint64_t n_windows,
+                         const uint64_t *mask_p, const uint64_t *mask_a, const uint64_t *mask_b,
+                         const impop_scan_params *params, impop_window_stats *out_host) {
+    impop_scan_plan *p = nullptr;
+    int rc = impop_scan_plan_create(ctx, m, windows, n_windows, mask_p, mask_a, mask_b, params, &p);
+    if (rc) return rc;
+    rc = impop_scan_plan_launch(p, nullptr);
+    if (!rc) rc = impop_scan_plan_fetch(p, out_host);
+    impop_scan_plan_destroy(p);
+    return rc;
+}
+
+IMPOP_API int impop_site_counts(impop_ctx *ctx, const impop_matrix *m, const uint64_t *mask, uint64_t site_begin,
+                                uint64_t site_end, uint32_t *out_host) {
+    REQUIRE(ctx && m, "impop_site_counts: NULL argument");
+    REQUIRE(site_begin <= site_end && site_end <= m->g.n_site, "impop_site_counts: bad site range");
+    const uint64_t W = site_end - site_begin;
+    if (!W) return IMPOP_OK;
+    REQUIRE(out_host, "impop_site_counts: out is NULL");
+    HIP_TRY(hipSetDevice(ctx->device));
+    std::vector<uint32_t> mk;
+    mask_to_dwords(mask, m->g.n_hap, m->g.wps, true, mk);
+    void *d = nullptr;
+    const size_t mask_bytes = ((size_t)m->g.wps * 4 + 255) / 256 * 256;
+    int rc = ctx_scratch(ctx, mask_bytes + W * 4, &d);
+    if (rc) return rc;
+    uint32_t *d_mask = (uint32_t *)d, *d_cnt = (uint32_t *)((char *)d + mask_bytes);
+    HIP_TRY(hipMemcpyAsync(d_mask, mk.data(), (size_t)m->g.wps * 4, hipMemcpyHostToDevice, ctx->stream));
+    const uint64_t nb = (site_end + 63) / 64 - site_begin / 64;
+    REQUIRE((nb + 3) / 4 < 0x7FFFFFFFull, "impop_site_counts: range too long");
+    hipLaunchKernelGGL(site_counts_kernel, dim3((uint32_t)((nb + 3) / 4)), dim3(256), 0, ctx->stream, m->d_sb, d_mask,
+                       m->g.wps, m->g.G, m->g.r, site_begin, site_end, d_cnt);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(out_host, d_cnt, W * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return IMPOP_OK;
+}

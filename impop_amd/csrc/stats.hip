@@ -1,0 +1,482 @@
+// stats.hip — pica2 / h-fst / af / tj_d arithmetic on the GPU + their C-ABI entry points for
+// a caller-supplied identity matrix (the .sim drop-in path).
+#include <math.h>
+#include <string.h>
+
+#include <vector>
+
+#include "stats_kernels.h"
+
+namespace impop {
+
+constexpr uint32_t NONE = 0xFFFFFFFFu;
+constexpr int ST = 256;  // threads per problem
+
+// deterministic block sums (wave butterfly, then waves in order)
+__device__ inline double block_sum_f64(double v, double *sh /*>= ST/64*/) {
+    v = wave_sum_f64(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double t = 0.0;
+    for (int w = 0; w < ST / 64; ++w) t += sh[w];
+    return t;
+}
+__device__ inline uint64_t block_sum_u64(uint64_t v, uint64_t *sh) {
+    v = wave_sum_u64(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    uint64_t t = 0;
+    for (int w = 0; w < ST / 64; ++w) t += sh[w];
+    return t;
+}
+
+// ---------------------------------------------------------------------------------------
+// pica2.analyze_similarity_matrix (pica2.py:60-169).  Elements are idx[0..n_el) (or 0..n_el
+// when idx == nullptr), already in lexicographic name order.
+// dynamic LDS: grp[n_el] u32 | rep[n_el] u32 | gsz[n_el] u32 | rowsum[n_el] f64
+__global__ __launch_bounds__(ST) void pica2_kernel(SimBatch batch, const uint32_t *__restrict__ idx, uint32_t n_el,
+                                                   double threshold, const uint64_t *__restrict__ seq_len,
+                                                   Pica2Out *__restrict__ out, uint32_t *__restrict__ group_of) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    double *rowsum = reinterpret_cast<double *>(lds_raw);
+    uint32_t *grp = reinterpret_cast<uint32_t *>(rowsum + n_el);
+    uint32_t *rep = grp + n_el;
+    uint32_t *gsz = rep + n_el;
+    __shared__ double shd[ST / 64];
+    __shared__ uint32_t sh_have;
+    const uint64_t prob = blockIdx.x;
+    const SimView S = sim_view(batch, prob);
+    const uint32_t tid = threadIdx.x;
+    for (uint32_t i = tid; i < n_el; i += ST) { grp[i] = NONE; gsz[i] = 0; }
+    if (tid == 0) sh_have = 0;
+    __syncthreads();
+    // Step 1 (pica2.py:94-112): greedy groups, seed = smallest remaining element
+    uint32_t G = 0;
+    for (uint32_t seed = 0; seed < n_el; ++seed) {
+        if (grp[seed] != NONE) continue;  // uniform across the workgroup
+        const uint32_t es = idx ? idx[seed] : seed;
+        uint32_t cnt = 0;
+        if (tid == 0) { grp[seed] = G; rep[G] = seed; cnt = 1; }
+        for (uint32_t o = seed + 1 + tid; o < n_el; o += ST) {
+            if (grp[o] != NONE) continue;
+            const double v = sim_get(S, es, idx ? idx[o] : o);
+            if (v == v && v > threshold) { grp[o] = G; ++cnt; }  // strict > (pica2.py:106)
+        }
+        if (cnt) atomicAdd(&gsz[G], cnt);
+        ++G;
+        __syncthreads();
+    }
+    // Step 2-3 (pica2.py:118-154): sum over group pairs of 2*(1-sim(rep_i,rep_j))*f_i*f_j
+    const double total = (double)n_el;
+    uint32_t have = 0;
+    for (uint32_t i = tid; i < G; i += ST) {
+        const uint32_t ri = idx ? idx[rep[i]] : rep[i];
+        const double fi = (double)gsz[i] / total;
+        double acc = 0.0;
+        for (uint32_t j = i + 1; j < G; ++j) {
+            const double s = sim_get(S, ri, idx ? idx[rep[j]] : rep[j]);
+            if (s != s) continue;  // missing pair skipped (pica2.py:132-134)
+            const double fj = (double)gsz[j] / total;
+            const double pv = (1 - s) * fi * fj;
+            acc += 2 * pv;
+            have = 1;
+        }
+        rowsum[i] = acc;
+    }
+    if (have) atomicOr(&sh_have, 1u);
+    __syncthreads();
+    if (tid == 0) {
+        double acc = 0.0;
+        for (uint32_t i = 0; i < G; ++i) acc += rowsum[i];
+        double pi = 0.0, pi_site = 0.0;
+        if (n_el != 0 && sh_have) {
+            pi = ((double)n_el / (double)(n_el - 1)) * acc;  // pica2.py:154
+            const uint64_t L = seq_len ? seq_len[prob] : 0;
+            pi_site = L ? pi / (double)L : __builtin_nan("");  // :163-164, None -> NaN
+        }
+        Pica2Out o;
+        o.pi = pi; o.pi_site = pi_site; o.n_groups = G; o.pad = 0;
+        out[prob] = o;
+    }
+    if (group_of)
+        for (uint32_t i = tid; i < n_el; i += ST) group_of[prob * n_el + i] = grp[i];
+    (void)shd;
+}
+
+// ---------------------------------------------------------------------------------------
+// h-fst.calculate_diversity / calculate_fst (h-fst.py:130-249)
+__global__ __launch_bounds__(ST) void hfst_kernel(SimBatch batch, const uint8_t *__restrict__ in_a,
+                                                  const uint8_t *__restrict__ in_b, const uint64_t *__restrict__ seq_len,
+                                                  HfstOut *__restrict__ out) {
+    __shared__ double shd[ST / 64];
+    __shared__ uint64_t shu[ST / 64];
+    const uint64_t prob = blockIdx.x;
+    const SimView S = sim_view(batch, prob);
+    const uint32_t n = batch.n, tid = threadIdx.x;
+    double accA = 0.0, accB = 0.0, accX = 0.0;
+    uint64_t cA = 0, mA = 0, cB = 0, mB = 0, cX = 0, mX = 0;
+    for (uint32_t i = tid; i < n; i += ST) {
+        const bool ai = in_a[i] && !in_b[i], bi = in_b[i] && !in_a[i];  // overlap leaves both (h-fst.py:181-185)
+        if (!ai && !bi) continue;
+        for (uint32_t j = 0; j < n; ++j) {
+            const bool aj = in_a[j] && !in_b[j], bj = in_b[j] && !in_a[j];
+            const bool wA = ai && aj && i < j, wB = bi && bj && i < j, wX = ai && bj;
+            if (!(wA || wB || wX)) continue;
+            const double s = sim_get(S, i, j);
+            const bool miss = s != s;
+            const double d = 1 - s;
+            if (wA) { if (miss) ++mA; else { accA += d; ++cA; } }
+            if (wB) { if (miss) ++mB; else { accB += d; ++cB; } }
+            if (wX) { if (miss) ++mX; else { accX += d; ++cX; } }
+        }
+    }
+    accA = block_sum_f64(accA, shd); accB = block_sum_f64(accB, shd); accX = block_sum_f64(accX, shd);
+    cA = block_sum_u64(cA, shu); mA = block_sum_u64(mA, shu);
+    cB = block_sum_u64(cB, shu); mB = block_sum_u64(mB, shu);
+    cX = block_sum_u64(cX, shu); mX = block_sum_u64(mX, shu);
+    if (tid == 0) {
+        const double pi_a = cA ? accA / (double)cA : 0.0;  // h-fst.py:168-171
+        const double pi_b = cB ? accB / (double)cB : 0.0;
+        const double dxy = cX ? accX / (double)cX : 0.0;
+        const double pi_xy = 0.5 * (pi_a + pi_b);                   // :203
+        const double fst = (dxy > 0) ? (dxy - pi_xy) / dxy : 0.0;   // :214-221
+        const uint64_t L = seq_len ? seq_len[prob] : 0;
+        HfstOut o;
+        if (L > 0) {  // :225-240
+            const double dl = (double)L;
+            o.v[0] = fst; o.v[1] = pi_a / dl; o.v[2] = pi_b / dl; o.v[3] = pi_xy / dl; o.v[4] = dxy / dl;
+            o.v[5] = (dxy - pi_xy) / dl;
+        } else {
+            o.v[0] = fst; o.v[1] = pi_a; o.v[2] = pi_b; o.v[3] = pi_xy; o.v[4] = dxy; o.v[5] = dxy - pi_xy;
+        }
+        o.cnt[0] = cA; o.cnt[1] = mA; o.cnt[2] = cB; o.cnt[3] = mB; o.cnt[4] = cX; o.cnt[5] = mX;
+        out[prob] = o;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// af.cluster (af.py:35-44): adjacency bits, then min-label propagation with pointer jumping
+__global__ void af_adjacency_kernel(SimBatch batch, double threshold, uint32_t words, uint32_t *__restrict__ adj) {
+    const uint32_t n = batch.n;
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (uint64_t)n * words) return;
+    const uint32_t i = (uint32_t)(t / words), w = (uint32_t)(t % words);
+    const SimView S = sim_view(batch, 0);
+    uint32_t bits = 0;
+    for (uint32_t b = 0; b < 32; ++b) {
+        const uint32_t j = 32 * w + b;
+        if (j >= n) break;
+        const double v = sim_get(S, i, j);
+        if (v == v && v >= threshold) bits |= 1u << b;  // non-strict (af.py:38)
+    }
+    adj[t] = bits;
+}
+
+// dynamic LDS: label[n] | size[n] | rank[n]
+__global__ __launch_bounds__(ST) void af_components_kernel(uint32_t n, uint32_t words, const uint32_t *__restrict__ adj,
+                                                           uint32_t *__restrict__ cluster_of, uint32_t *__restrict__ sizes,
+                                                           uint32_t *__restrict__ n_clusters) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    uint32_t *label = reinterpret_cast<uint32_t *>(lds_raw);
+    uint32_t *size = label + n;
+    uint32_t *rank = size + n;
+    __shared__ uint32_t changed, K;
+    const uint32_t tid = threadIdx.x;
+    for (uint32_t i = tid; i < n; i += ST) { label[i] = i; size[i] = 0; }
+    __syncthreads();
+    for (uint32_t iter = 0; iter <= n; ++iter) {  // bounded: labels only decrease
+        if (tid == 0) changed = 0;
+        __syncthreads();
+        for (uint32_t i = tid; i < n; i += ST) {
+            uint32_t m = label[i];
+            for (uint32_t w = 0; w < words; ++w) {
+                uint32_t bits = adj[(uint64_t)i * words + w];
+                while (bits) {
+                    const uint32_t j = 32 * w + (uint32_t)(__ffs(bits) - 1);
+                    bits &= bits - 1;
+                    const uint32_t lj = label[j];
+                    if (lj < m) m = lj;
+                    // symmetric relation: pull i's label into j as well (rows may be one-sided
+                    // when only one orientation of a pair is present in the table)
+                    if (label[i] < lj) { atomicMin(&label[j], label[i]); changed = 1; }
+                }
+            }
+            if (m < label[i]) { atomicMin(&label[i], m); changed = 1; }
+        }
+        __syncthreads();
+        for (uint32_t i = tid; i < n; i += ST) {
+            const uint32_t l = label[i], ll = label[l];
+            if (ll < l) { atomicMin(&label[i], ll); changed = 1; }
+        }
+        __syncthreads();
+        const uint32_t c = changed;
+        __syncthreads();
+        if (!c) break;
+    }
+    for (uint32_t i = tid; i < n; i += ST) atomicAdd(&size[label[i]], 1u);
+    if (tid == 0) K = 0;
+    __syncthreads();
+    // order roots by (-size, smallest member) (af.py:43); the root label IS the smallest member
+    for (uint32_t r = tid; r < n; r += ST) {
+        if (!size[r]) continue;
+        uint32_t rk = 0;
+        for (uint32_t q = 0; q < n; ++q) {
+            if (!size[q] || q == r) continue;
+            if (size[q] > size[r] || (size[q] == size[r] && q < r)) ++rk;
+        }
+        rank[r] = rk;
+        sizes[rk] = size[r];
+        atomicAdd(&K, 1u);
+    }
+    __syncthreads();
+    for (uint32_t i = tid; i < n; i += ST) cluster_of[i] = rank[label[i]];
+    if (tid == 0) *n_clusters = K;
+}
+
+// ---------------------------------------------------------------------------------------
+__global__ void tajima_kernel(const int64_t *__restrict__ n, const double *__restrict__ S, const double *__restrict__ pi,
+                              uint64_t count, double *__restrict__ D, double *__restrict__ comps) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const TajConsts c = tajima_consts(n[i]);
+    double num, den;
+    D[i] = tajima_d_from(c, S[i], pi[i], &num, &den);
+    if (comps) {
+        double *o = comps + i * 10;
+        o[0] = c.a1; o[1] = c.a2; o[2] = c.b1; o[3] = c.b2; o[4] = c.c1; o[5] = c.c2; o[6] = c.e1; o[7] = c.e2;
+        o[8] = num; o[9] = den;
+    }
+}
+
+__global__ void py_round_kernel(const double *__restrict__ x, uint64_t count, int nd, double *__restrict__ out) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) out[i] = py_round(x[i], nd);
+}
+
+int launch_pica2(impop_ctx *ctx, const SimBatch &b, uint64_t n_problems, const uint32_t *d_idx, uint32_t n_el,
+                 double threshold, const uint64_t *d_seq_len, Pica2Out *d_out, uint32_t *d_group_of) {
+    if (!n_problems) return IMPOP_OK;
+    const size_t lds = (size_t)n_el * (8 + 12) + 16;
+    REQUIRE(lds <= 150 * 1024, "pica2: %u elements exceed the LDS-resident grouping limit (7600)", n_el);
+    REQUIRE(n_problems < 0x7FFFFFFFull, "pica2: too many problems");
+    if (lds > 48 * 1024)
+        HIP_TRY(hipFuncSetAttribute((const void *)pica2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(pica2_kernel, dim3((uint32_t)n_problems), dim3(ST), lds, ctx->stream, b, d_idx, n_el, threshold,
+                       d_seq_len, d_out, d_group_of);
+    HIP_TRY(hipGetLastError());
+    return IMPOP_OK;
+}
+
+int launch_hfst(impop_ctx *ctx, const SimBatch &b, uint64_t n_problems, const uint8_t *d_in_a, const uint8_t *d_in_b,
+                const uint64_t *d_seq_len, HfstOut *d_out) {
+    if (!n_problems) return IMPOP_OK;
+    REQUIRE(n_problems < 0x7FFFFFFFull, "hfst: too many problems");
+    hipLaunchKernelGGL(hfst_kernel, dim3((uint32_t)n_problems), dim3(ST), 0, ctx->stream, b, d_in_a, d_in_b, d_seq_len,
+                       d_out);
+    HIP_TRY(hipGetLastError());
+    return IMPOP_OK;
+}
+
+int launch_af(impop_ctx *ctx, const SimBatch &b, double threshold, uint32_t *d_adj, uint32_t *d_cluster_of,
+              uint32_t *d_sizes, uint32_t *d_nclusters) {
+    const uint32_t n = b.n, words = (n + 31) / 32;
+    const size_t lds = (size_t)n * 12 + 16;
+    REQUIRE(lds <= 150 * 1024, "af: %u samples exceed the LDS-resident clustering limit (12700)", n);
+    if (n) {
+        const uint64_t total = (uint64_t)n * words;
+        hipLaunchKernelGGL(af_adjacency_kernel, dim3((uint32_t)((total + 255) / 256)), dim3(256), 0, ctx->stream, b,
+                           threshold, words, d_adj);
+        HIP_TRY(hipGetLastError());
+    }
+    if (lds > 48 * 1024)
+        HIP_TRY(hipFuncSetAttribute((const void *)af_components_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)lds));
+    hipLaunchKernelGGL(af_components_kernel, dim3(1), dim3(ST), lds, ctx->stream, n, words, d_adj, d_cluster_of, d_sizes,
+                       d_nclusters);
+    HIP_TRY(hipGetLastError());
+    return IMPOP_OK;
+}
+
+// scratch carve helper
+struct Carve {
+    char *base;
+    size_t off = 0;
+    explicit Carve(void *p) : base((char *)p) {}
+    template <typename T>
+    T *take(size_t count) {
+        off = (off + 255) / 256 * 256;
+        T *p = reinterpret_cast<T *>(base + off);
+        off += count * sizeof(T);
+        return p;
+    }
+};
+static size_t carve_size(std::initializer_list<size_t> sizes) {
+    size_t t = 0;
+    for (size_t s : sizes) t = (t + 255) / 256 * 256 + s;
+    return t + 256;
+}
+
+}  // namespace impop
+
+using namespace impop;
+
+IMPOP_API int impop_pi_from_identity(impop_ctx *ctx, const double *ident, uint32_t n, double threshold, int round_digits,
+                                     uint64_t seq_len, double *pi, double *pi_site, uint32_t *group_of,
+                                     uint32_t *n_groups) {
+    REQUIRE(ctx, "impop_pi_from_identity: ctx is NULL");
+    REQUIRE(n == 0 || ident, "impop_pi_from_identity: ident is NULL");
+    REQUIRE(round_digits <= 19, "impop_pi_from_identity: round_digits > 19 unsupported");
+    HIP_TRY(hipSetDevice(ctx->device));
+    const size_t nn = (size_t)n * n;
+    void *d = nullptr;
+    int rc = ctx_scratch(ctx, carve_size({nn * 8, 8, sizeof(Pica2Out), (size_t)n * 4}), &d);
+    if (rc) return rc;
+    Carve cv(d);
+    double *d_id = cv.take<double>(nn ? nn : 1);
+    uint64_t *d_L = cv.take<uint64_t>(1);
+    Pica2Out *d_out = cv.take<Pica2Out>(1);
+    uint32_t *d_grp = cv.take<uint32_t>(n ? n : 1);
+    if (nn) HIP_TRY(hipMemcpyAsync(d_id, ident, nn * 8, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(d_L, &seq_len, 8, hipMemcpyHostToDevice, ctx->stream));
+    SimBatch b{};
+    b.dense = d_id; b.gram = nullptr; b.stride = nn; b.ld = n; b.n = n; b.W = nullptr; b.kind = 0;
+    b.round_digits = round_digits < 0 ? -1 : round_digits;
+    rc = launch_pica2(ctx, b, 1, nullptr, n, threshold, d_L, d_out, d_grp);
+    if (rc) return rc;
+    Pica2Out o;
+    std::vector<uint32_t> g(n ? n : 1);
+    HIP_TRY(hipMemcpyAsync(&o, d_out, sizeof o, hipMemcpyDeviceToHost, ctx->stream));
+    if (n) HIP_TRY(hipMemcpyAsync(g.data(), d_grp, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (pi) *pi = o.pi;
+    if (pi_site) *pi_site = o.pi_site;
+    if (n_groups) *n_groups = o.n_groups;
+    if (group_of && n) memcpy(group_of, g.data(), (size_t)n * 4);
+    return IMPOP_OK;
+}
+
+IMPOP_API int impop_fst_from_identity(impop_ctx *ctx, const double *ident, uint32_t n, const uint8_t *in_a,
+                                      const uint8_t *in_b, uint64_t seq_len, int round_digits, double *out,
+                                      uint64_t *counts) {
+    REQUIRE(ctx && out, "impop_fst_from_identity: NULL argument");
+    REQUIRE(n == 0 || (ident && in_a && in_b), "impop_fst_from_identity: NULL input");
+    REQUIRE(round_digits <= 19, "impop_fst_from_identity: round_digits > 19 unsupported");
+    HIP_TRY(hipSetDevice(ctx->device));
+    const size_t nn = (size_t)n * n;
+    void *d = nullptr;
+    int rc = ctx_scratch(ctx, carve_size({nn * 8, 8, sizeof(HfstOut), (size_t)n, (size_t)n}), &d);
+    if (rc) return rc;
+    Carve cv(d);
+    double *d_id = cv.take<double>(nn ? nn : 1);
+    uint64_t *d_L = cv.take<uint64_t>(1);
+    HfstOut *d_out = cv.take<HfstOut>(1);
+    uint8_t *d_a = cv.take<uint8_t>(n ? n : 1);
+    uint8_t *d_b = cv.take<uint8_t>(n ? n : 1);
+    if (nn) HIP_TRY(hipMemcpyAsync(d_id, ident, nn * 8, hipMemcpyHostToDevice, ctx->stream));
+    if (n) {
+        HIP_TRY(hipMemcpyAsync(d_a, in_a, n, hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(hipMemcpyAsync(d_b, in_b, n, hipMemcpyHostToDevice, ctx->stream));
+    }
+    HIP_TRY(hipMemcpyAsync(d_L, &seq_len, 8, hipMemcpyHostToDevice, ctx->stream));
+    SimBatch b{};
+    b.dense = d_id; b.stride = nn; b.ld = n; b.n = n; b.round_digits = round_digits < 0 ? -1 : round_digits;
+    rc = launch_hfst(ctx, b, 1, d_a, d_b, d_L, d_out);
+    if (rc) return rc;
+    HfstOut o;
+    HIP_TRY(hipMemcpyAsync(&o, d_out, sizeof o, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    for (int k = 0; k < 6; ++k) out[k] = o.v[k];
+    if (counts)
+        for (int k = 0; k < 6; ++k) counts[k] = o.cnt[k];
+    return IMPOP_OK;
+}
+
+IMPOP_API int impop_cluster_from_identity(impop_ctx *ctx, const double *ident, uint32_t n, double threshold,
+                                          uint32_t *cluster_of, uint32_t *n_clusters, uint32_t *sizes) {
+    REQUIRE(ctx, "impop_cluster_from_identity: ctx is NULL");
+    REQUIRE(n == 0 || (ident && cluster_of), "impop_cluster_from_identity: NULL argument");
+    if (n == 0) {
+        if (n_clusters) *n_clusters = 0;
+        return IMPOP_OK;
+    }
+    HIP_TRY(hipSetDevice(ctx->device));
+    const size_t nn = (size_t)n * n;
+    const uint32_t words = (n + 31) / 32;
+    void *d = nullptr;
+    int rc = ctx_scratch(ctx, carve_size({nn * 8, (size_t)n * words * 4, (size_t)n * 4, (size_t)n * 4, 4}), &d);
+    if (rc) return rc;
+    Carve cv(d);
+    double *d_id = cv.take<double>(nn);
+    uint32_t *d_adj = cv.take<uint32_t>((size_t)n * words);
+    uint32_t *d_cl = cv.take<uint32_t>(n);
+    uint32_t *d_sz = cv.take<uint32_t>(n);
+    uint32_t *d_k = cv.take<uint32_t>(1);
+    HIP_TRY(hipMemcpyAsync(d_id, ident, nn * 8, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemsetAsync(d_sz, 0, (size_t)n * 4, ctx->stream));
+    SimBatch b{};
+    b.dense = d_id; b.stride = nn; b.ld = n; b.n = n; b.round_digits = -1;
+    rc = launch_af(ctx, b, threshold, d_adj, d_cl, d_sz, d_k);
+    if (rc) return rc;
+    std::vector<uint32_t> sz(n);
+    uint32_t K = 0;
+    HIP_TRY(hipMemcpyAsync(cluster_of, d_cl, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(sz.data(), d_sz, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(&K, d_k, 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (n_clusters) *n_clusters = K;
+    if (sizes) memcpy(sizes, sz.data(), (size_t)n * 4);
+    return IMPOP_OK;
+}
+
+IMPOP_API int impop_tajimas_d(impop_ctx *ctx, const int64_t *n, const double *S, const double *pi, uint64_t count,
+                              double *D, double *comps) {
+    REQUIRE(ctx, "impop_tajimas_d: ctx is NULL");
+    if (!count) return IMPOP_OK;
+    REQUIRE(n && S && pi && D, "impop_tajimas_d: NULL argument");
+    for (uint64_t i = 0; i < count; ++i) {
+        if (n[i] < 2) { set_error("n must be >= 2"); return IMPOP_E_INVALID; }                    // tj_d.py:48-49
+        if (S[i] < 0 || pi[i] < 0) { set_error("S and pi must be non-negative"); return IMPOP_E_INVALID; }  // :50-51
+    }
+    HIP_TRY(hipSetDevice(ctx->device));
+    void *d = nullptr;
+    int rc = ctx_scratch(ctx, carve_size({count * 8, count * 8, count * 8, count * 8, count * 80}), &d);
+    if (rc) return rc;
+    Carve cv(d);
+    int64_t *d_n = cv.take<int64_t>(count);
+    double *d_S = cv.take<double>(count), *d_pi = cv.take<double>(count), *d_D = cv.take<double>(count);
+    double *d_c = cv.take<double>(count * 10);
+    HIP_TRY(hipMemcpyAsync(d_n, n, count * 8, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(d_S, S, count * 8, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(d_pi, pi, count * 8, hipMemcpyHostToDevice, ctx->stream));
+    REQUIRE((count + 63) / 64 < 0x7FFFFFFFull, "impop_tajimas_d: too many triples");
+    hipLaunchKernelGGL(tajima_kernel, dim3((uint32_t)((count + 63) / 64)), dim3(64), 0, ctx->stream, d_n, d_S, d_pi, count,
+                       d_D, comps ? d_c : nullptr);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(D, d_D, count * 8, hipMemcpyDeviceToHost, ctx->stream));
+    if (comps) HIP_TRY(hipMemcpyAsync(comps, d_c, count * 80, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return IMPOP_OK;
+}
+
+IMPOP_API int impop_py_round(impop_ctx *ctx, const double *x, uint64_t count, int ndigits, double *out) {
+    REQUIRE(ctx, "impop_py_round: ctx is NULL");
+    if (!count) return IMPOP_OK;
+    REQUIRE(x && out, "impop_py_round: NULL argument");
+    REQUIRE(ndigits >= 0 && ndigits <= 19, "impop_py_round: ndigits must be 0..19");
+    HIP_TRY(hipSetDevice(ctx->device));
+    void *d = nullptr;
+    int rc = ctx_scratch(ctx, carve_size({count * 8, count * 8}), &d);
+    if (rc) return rc;
+    Carve cv(d);
+    double *d_x = cv.take<double>(count), *d_o = cv.take<double>(count);
+    HIP_TRY(hipMemcpyAsync(d_x, x, count * 8, hipMemcpyHostToDevice, ctx->stream));
+    REQUIRE((count + 255) / 256 < 0x7FFFFFFFull, "impop_py_round: too many values");
+    hipLaunchKernelGGL(py_round_kernel, dim3((uint32_t)((count + 255) / 256)), dim3(256), 0, ctx->stream, d_x, count,
+                       ndigits, d_o);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(out, d_o, count * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return IMPOP_OK;
+}

@@ -1,0 +1,80 @@
+// stats_kernels.h — the reference's identity-matrix statistics (pica2.py, h-fst.py, af.py,
+// tj_d.py) as one-workgroup-per-problem HIP kernels.  A "problem" is one identity matrix:
+// either dense doubles (the .sim drop-in path) or the integer Gram counts of a window
+// (pairwise.hip), from which identities are formed on the fly (never stored in HBM).
+#pragma once
+#include "device_utils.h"
+#include "internal.h"
+
+namespace impop {
+
+struct SimBatch {
+    const double *dense;   // problem p at dense + p*stride (n x ld doubles) or nullptr
+    const int32_t *gram;   // problem p at gram + p*stride (ld x ld int32) or nullptr
+    uint64_t stride;       // elements between consecutive problems
+    uint32_t ld;
+    uint32_t n;            // elements of the full matrix
+    const uint64_t *W;     // per-problem site count (gram mode)
+    int kind;
+    int round_digits;
+};
+
+struct SimView {
+    const double *dense;
+    const int32_t *gram;
+    uint32_t ld;
+    uint64_t W;
+    int kind;
+    int round_digits;
+};
+
+__device__ inline SimView sim_view(const SimBatch &b, uint64_t p) {
+    SimView v;
+    v.dense = b.dense ? b.dense + p * b.stride : nullptr;
+    v.gram = b.gram ? b.gram + p * b.stride : nullptr;
+    v.ld = b.ld;
+    v.W = b.W ? b.W[p] : 0;
+    v.kind = b.kind;
+    v.round_digits = b.round_digits;
+    return v;
+}
+
+// identity of the unordered pair {i, j}; NaN = pair absent (pica2.py:85-87 keying)
+__device__ inline double sim_get(const SimView &S, uint32_t i, uint32_t j) {
+    if (i > j) { const uint32_t t = i; i = j; j = t; }
+    double v;
+    if (S.dense) {
+        v = S.dense[(uint64_t)i * S.ld + j];
+    } else {
+        const int64_t I = S.gram[(uint64_t)i * S.ld + j];
+        const int64_t ai = S.gram[(uint64_t)i * S.ld + i], aj = S.gram[(uint64_t)j * S.ld + j];
+        if (S.kind == IMPOP_IDENTITY_MATCH) {
+            const int64_t H = ai + aj - 2 * I;
+            v = S.W ? (double)((int64_t)S.W - H) / (double)S.W : 1.0;
+        } else {
+            const int64_t d = ai + aj;
+            v = d ? (double)(2 * I) / (double)d : 1.0;
+        }
+    }
+    if (S.round_digits >= 0 && v == v) v = py_round(v, S.round_digits);
+    return v;
+}
+
+struct Pica2Out {
+    double pi, pi_site;
+    uint32_t n_groups, pad;
+};
+
+struct HfstOut {
+    double v[6];       // fst, pi_a, pi_b, pi_xy, dxy, da
+    uint64_t cnt[6];   // pairs_a, miss_a, pairs_b, miss_b, pairs_between, miss_between
+};
+
+int launch_pica2(impop_ctx *ctx, const SimBatch &b, uint64_t n_problems, const uint32_t *d_idx, uint32_t n_el,
+                 double threshold, const uint64_t *d_seq_len, Pica2Out *d_out, uint32_t *d_group_of);
+int launch_hfst(impop_ctx *ctx, const SimBatch &b, uint64_t n_problems, const uint8_t *d_in_a, const uint8_t *d_in_b,
+                const uint64_t *d_seq_len, HfstOut *d_out);
+int launch_af(impop_ctx *ctx, const SimBatch &b, double threshold, uint32_t *d_adj, uint32_t *d_cluster_of,
+              uint32_t *d_sizes, uint32_t *d_nclusters);
+
+}  // namespace impop

@@ -1,0 +1,357 @@
+"""Host-side objects over the C ABI: Context, BitMatrix, ScanPlan.
+
+Everything here is marshalling — numpy arrays in, numpy structured records out;
+all arithmetic runs in libimpop_hip.so on the GPU.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Iterable, Optional, Sequence
+
+import numpy as np
+
+from . import _lib
+from ._lib import (IDENTITY_DICE, IDENTITY_MATCH, KEEP_HAP_MAJOR, KEEP_SITE_BLOCKED, ImpopError, PairwiseParams,
+                   PairwiseStats, ScanParams, SynthParams, Window, WindowStats, check)
+
+STATS_DTYPE = np.dtype([
+    ("n_sites", "<u4"), ("s_all", "<u4"), ("s_p", "<u4"), ("s_a", "<u4"), ("s_b", "<u4"), ("flags", "<u4"),
+    ("sum_p", "<u8"), ("sum_a", "<u8"), ("sum_b", "<u8"), ("sum_ab", "<u8"),
+    ("pi", "<f8"), ("pi_site", "<f8"), ("pi_a", "<f8"), ("pi_b", "<f8"), ("pi_xy", "<f8"), ("dxy", "<f8"),
+    ("da", "<f8"), ("fst", "<f8"), ("tajima_d", "<f8")])
+assert STATS_DTYPE.itemsize == 128
+
+PAIRWISE_DTYPE = np.dtype([
+    ("pi", "<f8"), ("pi_site", "<f8"), ("fst", "<f8"), ("pi_a", "<f8"), ("pi_b", "<f8"), ("pi_xy", "<f8"),
+    ("dxy", "<f8"), ("da", "<f8"), ("tajima_d", "<f8"), ("n_groups", "<u4"), ("s_all", "<u4"), ("s_p", "<u4"),
+    ("n_sites", "<u4"), ("reserved", "<u8")])
+assert PAIRWISE_DTYPE.itemsize == 96
+
+WINDOW_DTYPE = np.dtype([("site_begin", "<u8"), ("site_end", "<u8"), ("seq_len", "<u8")])
+
+IDENTITY_KINDS = {"match": IDENTITY_MATCH, "dice": IDENTITY_DICE}
+
+
+def pack_hap_major(mat01) -> np.ndarray:
+    """0/1 array [n_hap, n_site] -> uint64 [n_hap, ceil(n_site/64)] (bit s&63 of word s>>6)."""
+    m = np.ascontiguousarray(mat01, dtype=np.uint8)
+    if m.ndim != 2:
+        raise ValueError("presence matrix must be 2-D [haplotype, site]")
+    n, W = m.shape
+    words = max((W + 63) // 64, 1)
+    pad = np.zeros((n, words * 64), dtype=np.uint8)
+    pad[:, :W] = m
+    return np.ascontiguousarray(np.packbits(pad, axis=1, bitorder="little")).view(np.uint64).reshape(n, words)
+
+
+def unpack_hap_major(bits: np.ndarray, n_site: int) -> np.ndarray:
+    b = np.ascontiguousarray(bits, dtype=np.uint64)
+    return np.unpackbits(b.view(np.uint8), axis=1, bitorder="little")[:, :n_site]
+
+
+def pack_mask(flags, n: int) -> np.ndarray:
+    """Length-n membership flags (bool / 0-1) -> n-bit uint64 bitset."""
+    f = np.ascontiguousarray(flags).astype(np.uint8).ravel()
+    if f.size != n:
+        raise ValueError(f"mask has {f.size} flags, expected {n}")
+    words = max((n + 63) // 64, 1)
+    pad = np.zeros(words * 64, dtype=np.uint8)
+    pad[:n] = f != 0
+    return np.packbits(pad, bitorder="little").view(np.uint64).copy()
+
+
+def mask_from_indices(indices, n: int) -> np.ndarray:
+    f = np.zeros(n, dtype=np.uint8)
+    f[np.asarray(list(indices), dtype=np.int64)] = 1
+    return pack_mask(f, n)
+
+
+def _mask_ptr(mask, n):
+    if mask is None:
+        return None, None
+    a = np.asarray(mask)
+    if a.dtype != np.uint64:  # flags; uint64 arrays are taken as ready-made bitsets
+        a = pack_mask(a, n)
+    elif a.size != max((n + 63) // 64, 1):
+        raise ValueError("bitset mask has the wrong number of words")
+    a = np.ascontiguousarray(a, dtype=np.uint64)
+    return a, a.ctypes.data_as(C.POINTER(C.c_uint64))
+
+
+def make_windows(windows) -> np.ndarray:
+    """[(begin, end[, seq_len])] or structured array -> WINDOW_DTYPE array.
+    seq_len defaults to end-begin (LENGTH=end-start, run_pica2_impg.sh:133)."""
+    if isinstance(windows, np.ndarray) and windows.dtype == WINDOW_DTYPE:
+        return np.ascontiguousarray(windows)
+    rows = list(windows)
+    out = np.zeros(len(rows), dtype=WINDOW_DTYPE)
+    for i, r in enumerate(rows):
+        out[i]["site_begin"], out[i]["site_end"] = int(r[0]), int(r[1])
+        out[i]["seq_len"] = int(r[2]) if len(r) > 2 and r[2] is not None else int(r[1]) - int(r[0])
+    return out
+
+
+def fixed_windows(n_site: int, size: int, step: Optional[int] = None, seq_len: Optional[int] = None) -> np.ndarray:
+    """bedtools-makewindows-style tiling (doc/how_pi.md:42); the last window is clipped."""
+    step = step or size
+    starts = np.arange(0, max(n_site, 1), step, dtype=np.uint64)
+    if step < size:
+        starts = starts[starts + np.uint64(1) <= np.uint64(n_site)]
+    out = np.zeros(len(starts), dtype=WINDOW_DTYPE)
+    out["site_begin"] = starts
+    out["site_end"] = np.minimum(starts + np.uint64(size), np.uint64(n_site))
+    out["seq_len"] = (out["site_end"] - out["site_begin"]) if seq_len is None else seq_len
+    return out[out["site_end"] > out["site_begin"]]
+
+
+class Context:
+    """One GPU + one HIP stream (impop_ctx)."""
+
+    def __init__(self, device: int = 0, stream: Optional[int] = None):
+        self._lib = _lib.load()
+        self._h = C.c_void_p()
+        check(self._lib.impop_ctx_create(int(device), C.c_void_p(stream) if stream else None, C.byref(self._h)))
+        self.device = int(device)
+
+    @property
+    def handle(self):
+        if not self._h:
+            raise ImpopError(_lib.E_INVALID, "context is closed")
+        return self._h
+
+    def device_name(self) -> str:
+        buf = C.create_string_buffer(128)
+        check(self._lib.impop_ctx_device_name(self.handle, buf, 128))
+        return buf.value.decode()
+
+    def synchronize(self) -> None:
+        check(self._lib.impop_ctx_synchronize(self.handle))
+
+    def close(self) -> None:
+        if self._h:
+            self._lib.impop_ctx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- matrices -----------------------------------------------------------------
+    def upload(self, bits_hap_major: np.ndarray, n_site: int, keep_hap_major: bool = True) -> "BitMatrix":
+        b = np.ascontiguousarray(bits_hap_major, dtype=np.uint64)
+        if b.ndim != 2:
+            raise ValueError("bits must be [n_hap, words]")
+        h = C.c_void_p()
+        keep = KEEP_SITE_BLOCKED | (KEEP_HAP_MAJOR if keep_hap_major else 0)
+        check(self._lib.impop_matrix_upload(self.handle, b.ctypes.data_as(C.POINTER(C.c_uint64)), b.shape[0], int(n_site),
+                                            b.shape[1], keep, C.byref(h)))
+        return BitMatrix(self, h)
+
+    def upload_dense(self, mat01, keep_hap_major: bool = True) -> "BitMatrix":
+        m = np.asarray(mat01)
+        return self.upload(pack_hap_major(m), m.shape[1], keep_hap_major)
+
+    def synthetic(self, n_hap: int, n_site: int, seed: int = 20251031, n_founder: int = 8, p_founder: float = 1e-3,
+                  p_private_word: float = 3.2e-3, keep_hap_major: bool = False) -> "BitMatrix":
+        p = SynthParams(int(seed), int(n_founder), float(p_founder), float(p_private_word))
+        h = C.c_void_p()
+        keep = KEEP_SITE_BLOCKED | (KEEP_HAP_MAJOR if keep_hap_major else 0)
+        check(self._lib.impop_matrix_synthetic(self.handle, int(n_hap), int(n_site), C.byref(p), keep, C.byref(h)))
+        return BitMatrix(self, h)
+
+    # ---- statistics on a given identity matrix (the .sim drop-in path) -----------------
+    def pi_from_identity(self, ident: np.ndarray, threshold: float, round_digits: Optional[int], seq_len: Optional[int]):
+        a = np.ascontiguousarray(ident, dtype=np.float64)
+        n = a.shape[0] if a.ndim == 2 else 0
+        pi, ps, G = C.c_double(), C.c_double(), C.c_uint32()
+        grp = np.zeros(max(n, 1), dtype=np.uint32)
+        check(self._lib.impop_pi_from_identity(self.handle, a.ctypes.data_as(C.POINTER(C.c_double)), n, float(threshold),
+                                               -1 if round_digits is None else int(round_digits), int(seq_len or 0),
+                                               C.byref(pi), C.byref(ps), grp.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                               C.byref(G)))
+        return pi.value, ps.value, grp[:n].copy(), G.value
+
+    def fst_from_identity(self, ident: np.ndarray, in_a, in_b, seq_len: Optional[int], round_digits: Optional[int]):
+        a = np.ascontiguousarray(ident, dtype=np.float64)
+        n = a.shape[0] if a.ndim == 2 else 0
+        fa = np.ascontiguousarray(in_a, dtype=np.uint8)
+        fb = np.ascontiguousarray(in_b, dtype=np.uint8)
+        out = np.zeros(6)
+        cnt = np.zeros(6, dtype=np.uint64)
+        check(self._lib.impop_fst_from_identity(self.handle, a.ctypes.data_as(C.POINTER(C.c_double)), n,
+                                                fa.ctypes.data_as(C.POINTER(C.c_uint8)), fb.ctypes.data_as(C.POINTER(C.c_uint8)),
+                                                int(seq_len) if seq_len and seq_len > 0 else 0,
+                                                -1 if round_digits is None else int(round_digits),
+                                                out.ctypes.data_as(C.POINTER(C.c_double)), cnt.ctypes.data_as(C.POINTER(C.c_uint64))))
+        return out, cnt
+
+    def tajimas_d(self, n, S, pi, components: bool = False):
+        n_a = np.ascontiguousarray(np.atleast_1d(n), dtype=np.int64)
+        S_a = np.ascontiguousarray(np.atleast_1d(S), dtype=np.float64)
+        pi_a = np.ascontiguousarray(np.atleast_1d(pi), dtype=np.float64)
+        cnt = n_a.size
+        D = np.zeros(cnt)
+        comps = np.zeros((cnt, 10)) if components else None
+        check(self._lib.impop_tajimas_d(self.handle, n_a.ctypes.data_as(C.POINTER(C.c_int64)),
+                                        S_a.ctypes.data_as(C.POINTER(C.c_double)), pi_a.ctypes.data_as(C.POINTER(C.c_double)),
+                                        cnt, D.ctypes.data_as(C.POINTER(C.c_double)),
+                                        comps.ctypes.data_as(C.POINTER(C.c_double)) if components else None))
+        return (D, comps) if components else D
+
+    def cluster_from_identity(self, ident: np.ndarray, threshold: float):
+        a = np.ascontiguousarray(ident, dtype=np.float64)
+        n = a.shape[0] if a.ndim == 2 else 0
+        cl = np.zeros(max(n, 1), dtype=np.uint32)
+        sz = np.zeros(max(n, 1), dtype=np.uint32)
+        K = C.c_uint32()
+        check(self._lib.impop_cluster_from_identity(self.handle, a.ctypes.data_as(C.POINTER(C.c_double)), n, float(threshold),
+                                                    cl.ctypes.data_as(C.POINTER(C.c_uint32)), C.byref(K),
+                                                    sz.ctypes.data_as(C.POINTER(C.c_uint32))))
+        return cl[:n].copy(), K.value, sz[: K.value].copy()
+
+    def py_round(self, x, ndigits: int) -> np.ndarray:
+        a = np.ascontiguousarray(np.atleast_1d(x), dtype=np.float64)
+        out = np.zeros_like(a)
+        check(self._lib.impop_py_round(self.handle, a.ctypes.data_as(C.POINTER(C.c_double)), a.size, int(ndigits),
+                                       out.ctypes.data_as(C.POINTER(C.c_double))))
+        return out
+
+
+class BitMatrix:
+    """A haplotype x site presence matrix resident in HBM (impop_matrix)."""
+
+    def __init__(self, ctx: Context, handle):
+        self.ctx = ctx
+        self._h = handle
+        n, s, b, bps = C.c_uint32(), C.c_uint64(), C.c_uint64(), C.c_uint32()
+        check(ctx._lib.impop_matrix_info(handle, C.byref(n), C.byref(s), C.byref(b), C.byref(bps)))
+        self.n_hap, self.n_site, self.device_bytes, self.bytes_per_site = n.value, s.value, b.value, bps.value
+
+    @property
+    def handle(self):
+        if not self._h:
+            raise ImpopError(_lib.E_INVALID, "matrix is freed")
+        return self._h
+
+    def free(self) -> None:
+        if self._h:
+            self.ctx._lib.impop_matrix_free(self.ctx.handle if self.ctx._h else None, self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+    def download(self, site_begin: int = 0, site_end: Optional[int] = None) -> np.ndarray:
+        site_end = self.n_site if site_end is None else site_end
+        words = max((site_end - site_begin + 63) // 64, 1)
+        out = np.zeros((self.n_hap, words), dtype=np.uint64)
+        check(self.ctx._lib.impop_matrix_download(self.ctx.handle, self.handle, int(site_begin), int(site_end),
+                                                  out.ctypes.data_as(C.POINTER(C.c_uint64)), words))
+        return out
+
+    def plan(self, windows, mask_p=None, mask_a=None, mask_b=None, d_pi_mode: int = 0, s_scope: int = 0,
+             tile_blocks: int = 0) -> "ScanPlan":
+        return ScanPlan(self, make_windows(windows), mask_p, mask_a, mask_b, d_pi_mode, s_scope, tile_blocks)
+
+    def scan(self, windows, mask_p=None, mask_a=None, mask_b=None, d_pi_mode: int = 0, s_scope: int = 0,
+             tile_blocks: int = 0) -> np.ndarray:
+        """pi + Hudson Fst + Tajima's D + S for every window in one streaming pass."""
+        p = self.plan(windows, mask_p, mask_a, mask_b, d_pi_mode, s_scope, tile_blocks)
+        try:
+            p.launch()
+            return p.fetch()
+        finally:
+            p.destroy()
+
+    def site_counts(self, site_begin: int, site_end: int, mask=None) -> np.ndarray:
+        out = np.zeros(max(site_end - site_begin, 0), dtype=np.uint32)
+        keep, ptr = _mask_ptr(mask, self.n_hap)
+        check(self.ctx._lib.impop_site_counts(self.ctx.handle, self.handle, ptr, int(site_begin), int(site_end),
+                                              out.ctypes.data_as(C.POINTER(C.c_uint32))))
+        return out
+
+    def pairwise_counts(self, site_begin: int, site_end: int) -> np.ndarray:
+        out = np.zeros((self.n_hap, self.n_hap), dtype=np.int32)
+        check(self.ctx._lib.impop_pairwise_counts(self.ctx.handle, self.handle, int(site_begin), int(site_end),
+                                                  out.ctypes.data_as(C.POINTER(C.c_int32))))
+        return out
+
+    def pairwise_identity(self, site_begin: int, site_end: int, kind: str = "match") -> np.ndarray:
+        out = np.zeros((self.n_hap, self.n_hap))
+        check(self.ctx._lib.impop_pairwise_identity(self.ctx.handle, self.handle, int(site_begin), int(site_end),
+                                                    IDENTITY_KINDS[kind], out.ctypes.data_as(C.POINTER(C.c_double))))
+        return out
+
+    def pairwise_scan(self, windows, mask_p=None, mask_a=None, mask_b=None, kind: str = "match", threshold: float = 0.99,
+                      round_digits: Optional[int] = None, d_pi_mode: int = 0, s_scope: int = 0) -> np.ndarray:
+        """Full pica2 / h-fst semantics (threshold grouping, rounding) per window from the bit matrix."""
+        w = make_windows(windows)
+        out = np.zeros(len(w), dtype=PAIRWISE_DTYPE)
+        prm = PairwiseParams(C.sizeof(PairwiseParams), IDENTITY_KINDS[kind], float(threshold),
+                             -1 if round_digits is None else int(round_digits), int(d_pi_mode), int(s_scope), 0)
+        kp, pp = _mask_ptr(mask_p, self.n_hap)
+        ka, pa = _mask_ptr(mask_a, self.n_hap)
+        kb, pb = _mask_ptr(mask_b, self.n_hap)
+        check(self.ctx._lib.impop_pairwise_scan(self.ctx.handle, self.handle, w.ctypes.data_as(C.POINTER(Window)), len(w),
+                                                pp, pa, pb, C.byref(prm), out.ctypes.data_as(C.POINTER(PairwiseStats))))
+        return out
+
+
+class ScanPlan:
+    """Pre-planned windowed scan (impop_scan_plan): tile tables live on the device, so
+    launch() is two kernel launches with no host synchronisation."""
+
+    def __init__(self, matrix: BitMatrix, windows: np.ndarray, mask_p, mask_a, mask_b, d_pi_mode, s_scope, tile_blocks):
+        self.matrix = matrix
+        self.windows = windows
+        lib = matrix.ctx._lib
+        prm = ScanParams(C.sizeof(ScanParams), int(d_pi_mode), int(s_scope), int(tile_blocks))
+        kp, pp = _mask_ptr(mask_p, matrix.n_hap)
+        ka, pa = _mask_ptr(mask_a, matrix.n_hap)
+        kb, pb = _mask_ptr(mask_b, matrix.n_hap)
+        self._h = C.c_void_p()
+        check(lib.impop_scan_plan_create(matrix.ctx.handle, matrix.handle, windows.ctypes.data_as(C.POINTER(Window)),
+                                         len(windows), pp, pa, pb, C.byref(prm), C.byref(self._h)))
+        t, b = C.c_uint64(), C.c_uint64()
+        check(lib.impop_scan_plan_info(self._h, C.byref(t), C.byref(b)))
+        self.n_tiles, self.bytes_streamed = t.value, b.value
+        self.n_windows = len(windows)
+
+    def launch(self, d_out: Optional[int] = None) -> None:
+        check(self.matrix.ctx._lib.impop_scan_plan_launch(self._h, C.c_void_p(d_out) if d_out else None))
+
+    def fetch(self) -> np.ndarray:
+        out = np.zeros(self.n_windows, dtype=STATS_DTYPE)
+        check(self.matrix.ctx._lib.impop_scan_plan_fetch(self._h, out.ctypes.data_as(C.POINTER(WindowStats))))
+        return out
+
+    def timing(self, enable: bool = True) -> None:
+        check(self.matrix.ctx._lib.impop_scan_plan_timing(self._h, 1 if enable else 0))
+
+    def elapsed(self):
+        """-> (summed streaming-kernel ms, launches) since timing(True)"""
+        t, k = C.c_double(), C.c_uint64()
+        check(self.matrix.ctx._lib.impop_scan_plan_elapsed(self._h, C.byref(t), C.byref(k)))
+        return t.value, k.value
+
+    def destroy(self) -> None:
+        if self._h:
+            self.matrix.ctx._lib.impop_scan_plan_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass

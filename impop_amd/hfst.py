@@ -1,0 +1,63 @@
+"""GPU-backed mirror of the reference's scripts/h-fst.py function API (h-fst.py:18-249)."""
+from __future__ import annotations
+
+import sys
+
+import numpy as np
+
+from .popnames import canonicalize_identifier, expand_population, read_subset_file  # noqa: F401
+from .runtime import default_context
+from .simfile import densify
+from .simfile import read_similarity_file_hfst as read_similarity_file  # noqa: F401  (h-fst.py:84)
+
+
+def _flags(names, members):
+    s = set(members)
+    return np.fromiter((1 if x in s else 0 for x in names), dtype=np.uint8, count=len(names))
+
+
+def calculate_diversity(similarities, seq_set1, seq_set2=None, round_digits=None, ctx=None):
+    """h-fst.calculate_diversity (h-fst.py:130-171) -> (mean, n_pairs, n_missing)."""
+    ctx = ctx or default_context()
+    names = sorted(set(seq_set1) | set(seq_set2 or ()) | {k for pair in similarities for k in pair})
+    dense = densify(similarities, names)
+    if seq_set2 is None:
+        out, cnt = ctx.fst_from_identity(dense, _flags(names, seq_set1), np.zeros(len(names), np.uint8), None, round_digits)
+        return float(out[1]), int(cnt[0]), int(cnt[1])
+    # between: members of both sets would be dropped by calculate_fst's overlap rule, which
+    # calculate_diversity itself does not apply — evaluate on de-duplicated copies
+    a, b = set(seq_set1), set(seq_set2)
+    if a & b:
+        raise ValueError("calculate_diversity(between) with overlapping sets: call calculate_fst instead")
+    out, cnt = ctx.fst_from_identity(dense, _flags(names, a), _flags(names, b), None, round_digits)
+    return float(out[4]), int(cnt[4]), int(cnt[5])
+
+
+def calculate_fst(similarities, pop_a, pop_b, sequence_length=None, round_digits=None, log_file=None, ctx=None):
+    """h-fst.calculate_fst (h-fst.py:173-249) -> dict(fst, pi_a, pi_b, pi_xy, dxy, da)."""
+    def log_print(msg):
+        if log_file:
+            print(msg, file=log_file)
+
+    overlap = pop_a & pop_b
+    if overlap:  # h-fst.py:181-185
+        print(f"Warning: {len(overlap)} sequences appear in both populations", file=sys.stderr)
+        pop_a = pop_a - overlap
+        pop_b = pop_b - overlap
+    ctx = ctx or default_context()
+    names = sorted(set(pop_a) | set(pop_b) | {k for pair in similarities for k in pair})
+    dense = densify(similarities, names)
+    L = sequence_length if (sequence_length and sequence_length > 0) else None
+    out, cnt = ctx.fst_from_identity(dense, _flags(names, pop_a), _flags(names, pop_b), L, round_digits)
+    log_print("FST Calculation")
+    log_print("=" * 50)
+    log_print(f"Population A: {len(pop_a)} sequences")
+    log_print(f"Population B: {len(pop_b)} sequences")
+    if round_digits is not None:
+        log_print(f"Rounding similarities to {round_digits} decimal places")
+    log_print(f"  pairs A = {int(cnt[0])} ({int(cnt[1])} missing), pairs B = {int(cnt[2])} ({int(cnt[3])} missing), "
+              f"pairs between = {int(cnt[4])} ({int(cnt[5])} missing)")
+    keys = ("fst", "pi_a", "pi_b", "pi_xy", "dxy", "da")
+    res = {k: float(v) for k, v in zip(keys, out)}
+    log_print(f"  FST = {res['fst']:.6f}")
+    return res

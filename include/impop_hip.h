@@ -1,0 +1,248 @@
+/*
+ * impop_hip.h — C ABI of libimpop_hip.so: the MI355X (gfx950) windowed
+ * population-statistics engine for impop's pairwise-diversity hot path.
+ *
+ * The reference (pangenome/impop) has no FFI: the path sits behind Python
+ * functions and CLIs.  Each entry point below names the
+ * reference interface it replaces (file:line relative to the reference root).
+ * The reference-side binding a maintainer would add is the ctypes stub shown in
+ * INTEGRATION.md; impop_amd/_lib.py is exactly that stub.
+ *
+ * Conventions
+ *  - extern "C", plain pointers and sizes only; no exceptions, no Python or
+ *    torch types cross the boundary.
+ *  - every function returns 0 on success or a negative impop_status; the
+ *    message is retrievable with impop_last_error() (thread-local).
+ *  - a context (impop_ctx) owns one HIP stream on one device; it is not
+ *    thread-safe, the library is re-entrant across contexts.
+ *  - host pointers are caller-owned; device memory lives behind opaque handles.
+ *  - haplotypes are indexed 0..n-1 in the caller's order; for the name-ordered
+ *    semantics of pica2.py/af.py the caller passes them in lexicographic name
+ *    order (the Python layer does).
+ *  - dense identity matrices are row-major double[n*n]; NaN marks a pair that
+ *    is absent from the .sim table (pica2.py:131-134, h-fst.py:152-153).
+ *  - all compute runs on the GPU; there is no CPU fallback.  Without a usable
+ *    gfx950 device impop_ctx_create fails with IMPOP_E_NODEVICE.
+ */
+#ifndef IMPOP_HIP_H
+#define IMPOP_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define IMPOP_ABI_VERSION 1
+
+typedef enum impop_status {
+    IMPOP_OK = 0,
+    IMPOP_E_INVALID = -1,   /* bad argument (also the reference's ValueError cases, tj_d.py:48-51) */
+    IMPOP_E_NODEVICE = -2,  /* no HIP device / wrong architecture */
+    IMPOP_E_HIP = -3,       /* a HIP runtime call failed */
+    IMPOP_E_NOMEM = -4,
+    IMPOP_E_UNSUPPORTED = -5
+} impop_status;
+
+typedef struct impop_ctx impop_ctx;
+typedef struct impop_matrix impop_matrix;
+typedef struct impop_scan_plan impop_scan_plan;
+
+/* ---- library / context -------------------------------------------------- */
+int impop_version(void);                 /* IMPOP_ABI_VERSION */
+const char *impop_last_error(void);      /* thread-local, never NULL */
+int impop_device_count(int *count);
+/* stream: an existing hipStream_t (e.g. torch's current stream) or NULL to
+ * create a private non-blocking stream. */
+int impop_ctx_create(int device, void *stream, impop_ctx **out);
+int impop_ctx_destroy(impop_ctx *ctx);
+int impop_ctx_synchronize(impop_ctx *ctx);
+/* device name/arch string of the context's device, e.g. "gfx950:sramecc+:xnack-" */
+int impop_ctx_device_name(impop_ctx *ctx, char *buf, size_t buflen);
+
+/* ---- presence matrix ------------------------------------------------------
+ * Replaces the per-window `impg similarity` -> .sim TSV -> read_similarity_file
+ * round trip (run_pica2_impg.sh:162-175, pica2.py:6-58, h-fst.py:84-119): the
+ * haplotype x site presence matrix stays resident in HBM.
+ *
+ * Interchange layout ("hap-major"): bits[i*row_stride_words + (s>>6)] bit (s&63)
+ * is 1 iff haplotype i carries the allele at site s.
+ * keep flags: which device layouts to materialise. */
+#define IMPOP_KEEP_SITE_BLOCKED 1u /* SB64 layout used by impop_scan (always kept) */
+#define IMPOP_KEEP_HAP_MAJOR 2u    /* hap-major copy needed by impop_pairwise_* */
+
+int impop_matrix_upload(impop_ctx *ctx, const uint64_t *bits_hap_major, uint32_t n_hap, uint64_t n_site,
+                        uint64_t row_stride_words, uint32_t keep_flags, impop_matrix **out);
+
+/* Synthetic matrix generated on the device (bench / tests; SURVEY.md §8d
+ * generator re-expressed as a counter-based hash so any window can be
+ * regenerated independently on the CPU): ancestral allele per site, n_founder
+ * lineages each differing at p_founder of sites, per-32-haplotype-word private
+ * flips with probability p_private_word. */
+typedef struct impop_synth_params {
+    uint64_t seed;
+    uint32_t n_founder;       /* 1..32 */
+    double p_founder;         /* per founder per site */
+    double p_private_word;    /* per (site, 32-haplotype word): one random bit flips */
+} impop_synth_params;
+int impop_matrix_synthetic(impop_ctx *ctx, uint32_t n_hap, uint64_t n_site, const impop_synth_params *p,
+                           uint32_t keep_flags, impop_matrix **out);
+
+/* Copy sites [site_begin, site_end) back to the host in hap-major layout
+ * (bit 0 of word 0 of each row = site_begin). */
+int impop_matrix_download(impop_ctx *ctx, const impop_matrix *m, uint64_t site_begin, uint64_t site_end,
+                          uint64_t *bits_hap_major_out, uint64_t row_stride_words);
+int impop_matrix_info(const impop_matrix *m, uint32_t *n_hap, uint64_t *n_site, uint64_t *device_bytes,
+                      uint32_t *bytes_per_site);
+int impop_matrix_free(impop_ctx *ctx, impop_matrix *m);
+
+/* ---- windowed scan: pi + Hudson Fst + Tajima's D + S in one pass ------------
+ * Replaces, per window, the chain run_pica2_impg.sh:175 / run_h-fst.sh:74 /
+ * run_tajd.sh:148,166,180, i.e. pica2.analyze_similarity_matrix (pica2.py:60)
+ * at threshold >= 1 (every haplotype its own group), h-fst.calculate_fst
+ * (h-fst.py:173) and tj_d.tajimas_d (tj_d.py:47) on the `match` identity
+ * sim_ij = (W - H_ij)/W of the window's W sites, using the exact identities
+ *   sum_{i<j in P} H_ij = sum_s c_P,s (n_P - c_P,s)
+ *   sum_{i in A, j in B} H_ij = sum_s [c_A,s (n_B - c_B,s) + c_B,s (n_A - c_A,s)]
+ * (SURVEY.md Appendix A.1), so one streaming pass over the bit matrix suffices. */
+typedef struct impop_window {
+    uint64_t site_begin;  /* first site of the window */
+    uint64_t site_end;    /* one past the last site */
+    uint64_t seq_len;     /* `-l` of pica2.py:177 / h-fst.py:278; 0 = not given */
+} impop_window;
+
+typedef struct impop_window_stats { /* 128 bytes, fixed layout */
+    uint32_t n_sites;     /* W */
+    uint32_t s_all;       /* #{s: 0 < c_s < n} over all rows (run_tajd.sh:126,148: un-subset graph) */
+    uint32_t s_p;         /* segregating within subset P */
+    uint32_t s_a, s_b;    /* segregating within A, within B */
+    uint32_t flags;       /* reserved, 0 */
+    uint64_t sum_p;       /* sum_s cP (nP - cP)      = sum_{i<j in P} H_ij */
+    uint64_t sum_a;       /* sum_s cA (nA - cA) */
+    uint64_t sum_b;       /* sum_s cB (nB - cB) */
+    uint64_t sum_ab;      /* sum_s cA(nB-cB) + cB(nA-cA) = sum_{A x B} H_ij */
+    double pi;            /* pica2.py:154  (mean over pairs in P of 1 - sim) */
+    double pi_site;       /* pica2.py:164  pi / seq_len; NaN when seq_len == 0 (None) */
+    double pi_a, pi_b, pi_xy, dxy, da; /* h-fst.py:233-249 (divided by seq_len when > 0) */
+    double fst;           /* h-fst.py:214-221 */
+    double tajima_d;      /* tj_d.py:47-69; NaN where the reference prints nan/NA */
+} impop_window_stats;
+
+typedef struct impop_scan_params {
+    uint32_t struct_size; /* sizeof(impop_scan_params) */
+    /* which pi feeds Tajima's D: 0 = as wired by run_tajd.sh:166-180 (per-site pi
+     * through the "%.8f" text round trip), 1 = per-site pi unrounded,
+     * 2 = mean pairwise differences pi*W (textbook; not what the reference does) */
+    int32_t d_pi_mode;
+    /* S used for D: 0 = all rows of the matrix (run_tajd.sh:126,148), 1 = within P */
+    int32_t s_scope;
+    uint32_t tile_blocks; /* 0 = default; 64-site blocks per work tile (tuning) */
+} impop_scan_params;
+
+/* Masks are n_hap-bit little-endian bitsets (uint64 words).  mask_p: the
+ * sample subset for pi / D (run_tajd.sh -l list; NULL = all haplotypes);
+ * mask_a / mask_b: populations for Hudson Fst (NULL = empty).  Haplotypes in
+ * both A and B are removed from both (h-fst.py:181-185). */
+int impop_scan_plan_create(impop_ctx *ctx, const impop_matrix *m, const impop_window *windows, uint64_t n_windows,
+                           const uint64_t *mask_p, const uint64_t *mask_a, const uint64_t *mask_b,
+                           const impop_scan_params *params, impop_scan_plan **out);
+/* Enqueue one pass over all windows on the context's stream (no host sync, no
+ * allocation: graph-capturable).  d_out: device buffer of n_windows records, or
+ * NULL to use the plan's internal buffer. */
+int impop_scan_plan_launch(impop_scan_plan *plan, void *d_out);
+/* Synchronise and copy the plan's internal result buffer to the host. */
+int impop_scan_plan_fetch(impop_scan_plan *plan, impop_window_stats *out_host);
+int impop_scan_plan_info(const impop_scan_plan *plan, uint64_t *n_tiles, uint64_t *bytes_streamed);
+/* Measurement aid: with timing enabled every launch brackets the streaming kernel
+ * (not the tiny epilogue) with hipEvents on the context's stream; elapsed() synchronises
+ * and returns the summed kernel time and the number of launches since enable/reset. */
+int impop_scan_plan_timing(impop_scan_plan *plan, int enable);
+int impop_scan_plan_elapsed(impop_scan_plan *plan, double *total_ms, uint64_t *launches);
+int impop_scan_plan_destroy(impop_scan_plan *plan);
+/* Convenience: create + launch + fetch + destroy. */
+int impop_scan(impop_ctx *ctx, const impop_matrix *m, const impop_window *windows, uint64_t n_windows,
+               const uint64_t *mask_p, const uint64_t *mask_a, const uint64_t *mask_b,
+               const impop_scan_params *params, impop_window_stats *out_host);
+
+/* Per-site allele counts c_s of the haplotypes in `mask` (NULL = all) for sites
+ * [site_begin, site_end): the per-site allele frequency is c_s / n. */
+int impop_site_counts(impop_ctx *ctx, const impop_matrix *m, const uint64_t *mask, uint64_t site_begin,
+                      uint64_t site_end, uint32_t *counts_out_host);
+
+/* ---- all-pairs path -------------------------------------------------------
+ * I_ij = #sites of the window carried by both i and j (the quantity behind
+ * `impg similarity`'s estimated.identity, run_pica2_impg.sh:162); a_i = I_ii.
+ * out: int32 [n_hap * n_hap] row-major on the host. */
+int impop_pairwise_counts(impop_ctx *ctx, const impop_matrix *m, uint64_t site_begin, uint64_t site_end,
+                          int32_t *out_host);
+
+#define IMPOP_IDENTITY_MATCH 0 /* (W - H_ij)/W, H = a_i + a_j - 2 I_ij */
+#define IMPOP_IDENTITY_DICE 1  /* 2 I_ij / (a_i + a_j); 0/0 -> 1.0 */
+
+/* Identity matrix of a window as doubles (what a .sim file would hold). */
+int impop_pairwise_identity(impop_ctx *ctx, const impop_matrix *m, uint64_t site_begin, uint64_t site_end,
+                            int identity_kind, double *out_host);
+
+/* Full pica2 / h-fst / af semantics (thresholds, rounding, grouping) for a
+ * batch of windows straight from the bit matrix; identity never leaves the GPU. */
+typedef struct impop_pairwise_params {
+    uint32_t struct_size;
+    int32_t identity_kind;   /* IMPOP_IDENTITY_* */
+    double threshold;        /* pica2 -t (pica2.py:175) */
+    int32_t round_digits;    /* pica2 -r / h-fst -r; < 0 = none */
+    int32_t d_pi_mode;       /* as impop_scan_params */
+    int32_t s_scope;
+    uint32_t reserved;
+} impop_pairwise_params;
+typedef struct impop_pairwise_stats { /* 96 bytes */
+    double pi, pi_site;                      /* pica2.py:154,164 on subset P with grouping */
+    double fst, pi_a, pi_b, pi_xy, dxy, da;  /* h-fst.py:233-249 */
+    double tajima_d;                         /* tj_d.py:47 wired per d_pi_mode / s_scope */
+    uint32_t n_groups;                       /* pica2.py:114 */
+    uint32_t s_all, s_p, n_sites;
+    uint64_t reserved;
+} impop_pairwise_stats;
+int impop_pairwise_scan(impop_ctx *ctx, const impop_matrix *m, const impop_window *windows, uint64_t n_windows,
+                        const uint64_t *mask_p, const uint64_t *mask_a, const uint64_t *mask_b,
+                        const impop_pairwise_params *params, impop_pairwise_stats *out_host);
+
+/* ---- statistics on a given identity matrix (the .sim drop-in path) ---------
+ * These take what read_similarity_file (pica2.py:6-58, h-fst.py:84-119) yields,
+ * densified by the caller, and run the reference's arithmetic on the GPU. */
+
+/* pica2.analyze_similarity_matrix (pica2.py:60-169).  seq_len 0 = None.
+ * group_of (nullable, n entries): 0-based index of each element's group in the
+ * reference's sorted group order.  Seed of each greedy group = smallest
+ * remaining index (the reference's set.pop() order is unspecified, pica2.py:100). */
+int impop_pi_from_identity(impop_ctx *ctx, const double *ident, uint32_t n, double threshold, int round_digits,
+                           uint64_t seq_len, double *pi, double *pi_site, uint32_t *group_of, uint32_t *n_groups);
+
+/* h-fst.calculate_fst (h-fst.py:173-249).  in_a / in_b: n membership flags.
+ * out[6] = fst, pi_a, pi_b, pi_xy, dxy, da.
+ * counts[6] = pairs_a, missing_a, pairs_b, missing_b, pairs_between, missing_between. */
+int impop_fst_from_identity(impop_ctx *ctx, const double *ident, uint32_t n, const uint8_t *in_a,
+                            const uint8_t *in_b, uint64_t seq_len, int round_digits, double *out,
+                            uint64_t *counts);
+
+/* tj_d.tajimas_d (tj_d.py:47-69) for `count` (n, S, pi) triples.  comps
+ * (nullable): count x 10 doubles a1,a2,b1,b2,c1,c2,e1,e2,numerator,denominator.
+ * Returns IMPOP_E_INVALID (message = the reference's ValueError text) if any
+ * triple has n < 2, S < 0 or pi < 0; nothing is written in that case. */
+int impop_tajimas_d(impop_ctx *ctx, const int64_t *n, const double *S, const double *pi, uint64_t count,
+                    double *D, double *comps);
+
+/* af.cluster (af.py:35-44): connected components of {identity >= threshold}
+ * ordered by (-size, members); cluster_of[i] = 0-based cluster rank (c1 = 0),
+ * sizes (nullable): n entries, first n_clusters valid. */
+int impop_cluster_from_identity(impop_ctx *ctx, const double *ident, uint32_t n, double threshold,
+                                uint32_t *cluster_of, uint32_t *n_clusters, uint32_t *sizes);
+
+/* CPython round(x, ndigits) (pica2.py:83, h-fst.py:150) evaluated on the GPU,
+ * exposed so that the device implementation can be fuzzed against CPython. */
+int impop_py_round(impop_ctx *ctx, const double *x, uint64_t count, int ndigits, double *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* IMPOP_HIP_H */

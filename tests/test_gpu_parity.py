@@ -1,0 +1,340 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP engine, called through the C ABI,
+against the CPU oracle on the same seeded inputs and against the goldens captured from the
+real reference.  Integers bit-exact; pi / Fst / D within 1e-9 relative (north_star)."""
+import math
+import random
+
+import numpy as np
+import pytest
+
+from conftest import fh, golden_bits, golden_counts, load_golden, rel_close
+from synth_ref import synth_matrix
+
+pytestmark = pytest.mark.gpu
+
+REL = 1e-9  # tolerance stated by BASELINE.json north_star for pi / Fst / D
+INT_KEYS = ("n_sites", "s_all", "s_p", "s_a", "s_b", "sum_p", "sum_a", "sum_b", "sum_ab")
+DBL_KEYS = ("pi", "pi_site", "pi_a", "pi_b", "pi_xy", "dxy", "da", "fst", "tajima_d")
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import impop_amd
+    c = impop_amd.Context(0)
+    assert c.device_name().startswith("gfx950")
+    yield c
+    c.close()
+
+
+def founder_matrix(rng, n, W, nf=6, pf=0.01, pp=0.002):
+    anc = rng.integers(0, 2, size=W, dtype=np.uint8)
+    f = np.repeat(anc[None, :], nf, axis=0) ^ (rng.random((nf, W)) < pf).astype(np.uint8)
+    m = f[rng.integers(0, nf, size=n)].copy()
+    if pp > 0:
+        m ^= (rng.random((n, W)) < pp).astype(np.uint8)
+    return m
+
+
+def check_record(got, want, where):
+    for k in INT_KEYS:
+        assert int(got[k]) == int(want[k]), (where, k, int(got[k]), int(want[k]))
+    for k in DBL_KEYS:
+        assert rel_close(float(got[k]), float(want[k]), REL, 1e-300), (where, k, float(got[k]), float(want[k]))
+
+
+def test_py_round_device_matches_cpython(ctx):
+    rnd = random.Random(3)
+    vals = [0.999985, 0.999975, 0.99999499999, 0.5, 1.5, 2.5, 0.125, 1e-9, 0.0, 1.0, 0.99995, 0.9995, 2.675,
+            1.0000000000000002, 2.093456789e-05, 123456.7890125, -0.5, -2.675, 5e-324, 1e300, 4503599627370497.0]
+    for _ in range(60000):
+        k = rnd.randint(0, 3)
+        if k == 0:
+            vals.append(rnd.random())
+        elif k == 1:
+            vals.append(1.0 - rnd.random() * 1e-3)
+        elif k == 2:
+            vals.append(rnd.randint(0, 10 ** 6) / 10 ** rnd.randint(1, 7) + rnd.choice([0, 5e-7, 5e-6, 5e-9]))
+        else:
+            vals.append(rnd.random() * 10 ** rnd.randint(-10, 3))
+    x = np.array(vals)
+    for nd in (0, 2, 3, 5, 8):
+        got = ctx.py_round(x, nd)
+        want = np.array([round(float(v), nd) for v in x])
+        bad = np.nonzero(~((got == want) | (np.isnan(got) & np.isnan(want))))[0]
+        assert bad.size == 0, (nd, x[bad[:5]], got[bad[:5]], want[bad[:5]])
+
+
+def test_tajima_golden_device(ctx):
+    g = load_golden("tajima.json")
+    n = [c["n"] for c in g["cases"]]
+    S = [fh(c["S"]) for c in g["cases"]]
+    pi = [fh(c["pi"]) for c in g["cases"]]
+    D, comps = ctx.tajimas_d(n, S, pi, components=True)
+    for i, c in enumerate(g["cases"]):
+        assert rel_close(float(D[i]), fh(c["D"]), 1e-12), (c, D[i])
+        for got, w in zip(comps[i], c["comps"]):
+            assert rel_close(float(got), fh(w), 1e-12)
+    from impop_amd import tj_d
+    for e in g["errors"]:
+        with pytest.raises(ValueError) as ei:
+            tj_d.tajimas_d(e["n"], e["S"], e["pi"], ctx=ctx)
+        assert str(ei.value) == e["error"]
+    assert tj_d.tajimas_d(446, 20.0, 0.59146123, ctx=ctx) == pytest.approx(-1.9926482274156396, rel=1e-13)
+
+
+def test_roundtrip_upload_download(ctx):
+    rng = np.random.default_rng(11)
+    import impop_amd
+    for n, W in ((1, 1), (5, 63), (33, 64), (130, 777), (465, 1000), (600, 130)):
+        m = rng.integers(0, 2, size=(n, W), dtype=np.uint8)
+        bm = ctx.upload_dense(m)
+        assert (impop_amd.unpack_hap_major(bm.download(), W) == m).all()
+        a, b = W // 3, W - W // 5
+        assert (impop_amd.unpack_hap_major(bm.download(a, b), b - a) == m[:, a:b]).all()
+        cnt = bm.site_counts(0, W)
+        assert (cnt == m.sum(0)).all()
+        bm.free()
+
+
+def test_scan_vs_oracle_and_golden(ctx, oracle):
+    g = load_golden("bitmatrix.json")
+    for mrec in g["matrices"]:
+        n, W, L = mrec["n"], mrec["W"], mrec["L"]
+        bits = golden_bits(mrec)
+        bm = ctx.upload(bits, W)
+        inA, inB = np.array(mrec["in_a"], np.uint8), np.array(mrec["in_b"], np.uint8)
+        ones = np.ones(n, np.uint8)
+        wins = [(0, W, L), (0, W // 2, L), (W // 3, W, 0), (5, 5, 10), (W - 1, W, 1)]
+        got = bm.scan(wins, None, inA, inB)
+        for (s0, s1, sl), r in zip(wins, got):
+            want = oracle.window_allpairs(bits, n, s0, s1, oracle.pack_mask(ones), oracle.pack_mask(inA),
+                                          oracle.pack_mask(inB), sl)
+            check_record(r, want, (mrec["name"], s0, s1))
+        # against the real reference's numbers
+        r = got[0]
+        ref_p = [c for c in mrec["kinds"]["match"]["pica2"] if fh(c["threshold"]) == 1.0 and c["round"] is None and c["L"] == L][0]
+        assert rel_close(float(r["pi"]), fh(ref_p["pi"]), REL) and rel_close(float(r["pi_site"]), fh(ref_p["pi_site"]), REL)
+        ref_h = [c for c in mrec["kinds"]["match"]["hfst"] if c["L"] == L and c["round"] is None][0]["out"]
+        for k in ("fst", "pi_a", "pi_b", "pi_xy", "dxy", "da"):
+            assert rel_close(float(r[k]), fh(ref_h[k]), REL, 1e-300), (mrec["name"], k)
+        assert int(r["s_all"]) == mrec["S_all"]
+        assert rel_close(float(r["tajima_d"]), fh(mrec["tajd_chain"]["D"]), REL)
+        # overlapping populations are removed from both (h-fst.py:181-185)
+        ov = mrec["kinds"]["match"]["hfst_overlap"]
+        inB2 = inB.copy()
+        for nm in ov["extra_in_b"]:
+            inB2[mrec["names"].index(nm)] = 1
+        r2 = bm.scan([(0, W, ov["L"])], None, inA, inB2)[0]
+        for k in ("fst", "pi_a", "pi_b", "pi_xy", "dxy", "da"):
+            assert rel_close(float(r2[k]), fh(ov["out"][k]), REL, 1e-300)
+        bm.free()
+
+
+@pytest.mark.parametrize("n,W", [(465, 5000), (31, 700), (64, 640), (97, 1300), (513, 900), (1030, 400)])
+def test_scan_random_shapes(ctx, oracle, n, W):
+    rng = np.random.default_rng(n * 7919 + W)
+    m = founder_matrix(rng, n, W)
+    bits = oracle.pack_hap_major(m)
+    bm = ctx.upload(bits, W)
+    inP = (rng.random(n) < 0.8).astype(np.uint8)
+    inA = (rng.random(n) < 0.3).astype(np.uint8)
+    inB = ((rng.random(n) < 0.3) & (inA == 0)).astype(np.uint8)
+    # ragged, overlapping, unaligned, empty and single-site windows in one plan
+    wins = [(0, W, W), (1, W - 1, 50000), (63, 65, 2), (64, 128, 64), (100, 100, 7), (W - 1, W, 1), (0, 1, 1),
+            (W // 2, W, 0), (W // 4, 3 * W // 4, 123), (W // 4 + 1, 3 * W // 4 + 1, 123)]
+    for tile_blocks, d_pi_mode, s_scope in ((0, 0, 0), (1, 1, 1), (3, 2, 0)):
+        got = bm.scan(wins, inP, inA, inB, d_pi_mode=d_pi_mode, s_scope=s_scope, tile_blocks=tile_blocks)
+        for (s0, s1, sl), r in zip(wins, got):
+            want = oracle.window_sitecount(bits, n, s0, s1, oracle.pack_mask(inP), oracle.pack_mask(inA),
+                                           oracle.pack_mask(inB), sl, d_pi_mode, s_scope)
+            check_record(r, want, (n, W, s0, s1, tile_blocks))
+    # permutation invariance of haplotype order (integers exact)
+    perm = rng.permutation(n)
+    bm2 = ctx.upload(oracle.pack_hap_major(m[perm]), W)
+    a = bm.scan(wins[:3], inP, inA, inB)
+    b = bm2.scan(wins[:3], inP[perm], inA[perm], inB[perm])
+    for k in INT_KEYS:
+        assert (a[k] == b[k]).all()
+    bm.free(); bm2.free()
+
+
+def test_scan_allpairs_oracle_n465(ctx, oracle):
+    """BASELINE config 2/3 shape at a size the all-pairs oracle finishes in seconds."""
+    n, W = 465, 6000
+    rng = np.random.default_rng(465)
+    m = founder_matrix(rng, n, W, nf=8, pf=1e-3, pp=1e-4)
+    bits = oracle.pack_hap_major(m)
+    bm = ctx.upload(bits, W)
+    inA = np.zeros(n, np.uint8); inA[:140] = 1
+    inB = np.zeros(n, np.uint8); inB[140:240] = 1
+    wins = [(0, 3000, 3000), (3000, 6000, 3000)]
+    got = bm.scan(wins, None, inA, inB)
+    ones = oracle.pack_mask(np.ones(n, np.uint8))
+    for (s0, s1, sl), r in zip(wins, got):
+        want = oracle.window_allpairs(bits, n, s0, s1, ones, oracle.pack_mask(inA), oracle.pack_mask(inB), sl)
+        check_record(r, want, (s0, s1))
+    bm.free()
+
+
+def test_sliding_window_additivity(ctx):
+    """size-independent property: integer sums of a window equal the sums of its parts."""
+    n, W = 465, 64 * 700 + 17
+    bm = ctx.synthetic(n, W, seed=5)
+    inA = np.zeros(n, np.uint8); inA[:140] = 1
+    inB = np.zeros(n, np.uint8); inB[140:240] = 1
+    import impop_amd
+    slide = impop_amd.fixed_windows(W, 10000, 5000)
+    halves = impop_amd.fixed_windows(W, 5000)
+    a = bm.scan(slide, None, inA, inB)
+    h = bm.scan(halves, None, inA, inB)
+    for i, w in enumerate(slide):
+        j = int(w["site_begin"]) // 5000
+        parts = h[j: j + 2] if int(w["site_end"]) - int(w["site_begin"]) > 5000 else h[j: j + 1]
+        for k in INT_KEYS:
+            assert int(a[i][k]) == int(parts[k].sum()), (i, k)
+    whole = bm.scan([(0, W)], None, inA, inB)[0]
+    for k in INT_KEYS:
+        assert int(whole[k]) == int(h[k].sum())
+    bm.free()
+
+
+def test_synthetic_generator_matches_numpy(ctx, oracle):
+    import impop_amd
+    n, W = 465, 3000
+    bm = ctx.synthetic(n, W, seed=77, keep_hap_major=True)
+    want = synth_matrix(n, 0, W, seed=77)
+    got = impop_amd.unpack_hap_major(bm.download(), W)
+    assert (got == want).all()
+    # a window in the middle of a larger matrix regenerates identically (counter-based)
+    bm2 = ctx.synthetic(n, 100000, seed=77)
+    got2 = impop_amd.unpack_hap_major(bm2.download(64000 + 13, 64000 + 13 + 500), 500)
+    assert (got2 == synth_matrix(n, 64013, 64513, seed=77)).all()
+    # statistics look like the SURVEY generator: S around 5 % of sites
+    r = bm2.scan([(0, 50000)])[0]
+    assert 1500 < int(r["s_all"]) < 4000
+    bm.free(); bm2.free()
+
+
+def test_pairwise_counts_and_identity(ctx, oracle):
+    g = load_golden("bitmatrix.json")
+    for mrec in g["matrices"]:
+        n, W = mrec["n"], mrec["W"]
+        bits = golden_bits(mrec)
+        bm = ctx.upload(bits, W)
+        I = bm.pairwise_counts(0, W)
+        assert (I.astype(np.int64) == golden_counts(mrec)).all()
+        for s0, s1 in ((0, W), (3, W - 5), (31, 97), (64, 64)):
+            assert (bm.pairwise_counts(s0, s1).astype(np.int64) == oracle.pairwise_counts(bits, n, s0, s1)).all()
+        for kind, kid in (("match", 0), ("dice", 1)):
+            sim = bm.pairwise_identity(0, W, kind)
+            assert (sim == oracle.identity(golden_counts(mrec), W, kid)).all()  # one IEEE division each
+        bm.free()
+
+
+def test_pairwise_scan_vs_reference_goldens(ctx, oracle):
+    g = load_golden("bitmatrix.json")
+    for mrec in g["matrices"]:
+        n, W, L = mrec["n"], mrec["W"], mrec["L"]
+        bm = ctx.upload(golden_bits(mrec), W)
+        inA, inB = np.array(mrec["in_a"], np.uint8), np.array(mrec["in_b"], np.uint8)
+        for kind in ("match", "dice"):
+            out = mrec["kinds"][kind]
+            for c in out["pica2"]:
+                if c["L"] is None:
+                    continue
+                r = bm.pairwise_scan([(0, W, c["L"])], None, inA, inB, kind=kind, threshold=fh(c["threshold"]),
+                                     round_digits=c["round"])[0]
+                assert rel_close(float(r["pi"]), fh(c["pi"]), REL, 1e-300), (mrec["name"], kind, c)
+                assert rel_close(float(r["pi_site"]), fh(c["pi_site"]), REL, 1e-300)
+            for c in out["hfst"]:
+                r = bm.pairwise_scan([(0, W, c["L"] or 0)], None, inA, inB, kind=kind, threshold=1.0,
+                                     round_digits=c["round"])[0]
+                for k, v in c["out"].items():
+                    assert rel_close(float(r[k]), fh(v), REL, 1e-300), (mrec["name"], kind, k)
+        # batch of windows + subset P vs the oracle's dense functions
+        rng = np.random.default_rng(3)
+        inP = (rng.random(n) < 0.7).astype(np.uint8)
+        wins = [(0, W, W), (W // 3, W, 777), (10, W // 2, 0)]
+        res = bm.pairwise_scan(wins, inP, inA, inB, kind="match", threshold=0.995, round_digits=4, d_pi_mode=1, s_scope=1)
+        bits = golden_bits(mrec)
+        for (s0, s1, sl), r in zip(wins, res):
+            sim = oracle.identity(oracle.pairwise_counts(bits, n, s0, s1), s1 - s0, 0)
+            idx = np.nonzero(inP)[0]
+            pi, ps, _, G = oracle.pica2(sim[np.ix_(idx, idx)], 0.995, sl, 4)
+            assert rel_close(float(r["pi"]), pi, REL, 1e-300) and rel_close(float(r["pi_site"]), ps, REL, 1e-300)
+            assert int(r["n_groups"]) == G
+            h, _ = oracle.hfst(sim, inA, inB, sl, 4)
+            for k, v in h.items():
+                assert rel_close(float(r[k]), v, REL, 1e-300)
+        bm.free()
+
+
+def test_identity_functions_vs_goldens(ctx, oracle):
+    """The .sim drop-in path: reference-API mirrors on the reference's own data structures."""
+    from impop_amd import af, hfst, pica2
+    g = load_golden("six_seq.json")
+    rows = [(a, b, fh(v)) for a, b, v in g["rows"]]
+    d = {((a, b) if a <= b else (b, a)): v for a, b, v in rows}
+    names = sorted({r[0] for r in rows} | {r[1] for r in rows})
+    for c in g["pica2"]:
+        pi, ps = pica2.analyze_similarity_matrix(dict(d), set(names), len(d), fh(c["threshold"]), c["L"], None, c["round"], ctx=ctx)
+        assert rel_close(pi, fh(c["pi"]), REL) and rel_close(ps, fh(c["pi_site"]), REL)
+    A = {s for s in names if "popA" in s}
+    B = {s for s in names if "popB" in s}
+    for c in g["hfst"]:
+        r = hfst.calculate_fst(d, set(A), set(B), c["L"], c["round"], ctx=ctx)
+        for k, v in c["out"].items():
+            assert rel_close(r[k], fh(v), REL), (k, r[k], fh(v))
+    for c in g["af"]:
+        cl = af.cluster(rows, names, fh(c["threshold"]), ctx=ctx)
+        assert [sorted(x) for x in cl] == c["clusters"]
+    # ragged table (missing pairs) and degenerate inputs
+    rg = load_golden("ragged.json")
+    names = rg["names"]
+    sim = np.array([[fh(v) for v in row] for row in rg["sim"]])
+    d = {(names[i], names[j]): float(sim[i, j]) for i in range(len(names)) for j in range(i, len(names))}
+    for a, b in rg["dropped"]:
+        d.pop((a, b), None)
+    for c in rg["pica2"]:
+        pi, ps = pica2.analyze_similarity_matrix(dict(d), set(names), len(d), fh(c["threshold"]), c["L"], None, c["round"], ctx=ctx)
+        assert rel_close(pi, fh(c["pi"]), REL) and rel_close(ps, fh(c["pi_site"]), REL)
+    for c in rg["hfst"]:
+        r = hfst.calculate_fst(d, set(c["a"]), set(c["b"]), c["L"], None, ctx=ctx)
+        for k, v in c["out"].items():
+            assert rel_close(r[k], fh(v), REL)
+    assert pica2.analyze_similarity_matrix({}, set(), 0, 1.0, 100, None, None, ctx=ctx) == (0.0, 0.0)
+    assert pica2.analyze_similarity_matrix({("x", "x"): 1.0}, {"x"}, 1, 1.0, 100, None, None, ctx=ctx) == (0.0, 0.0)
+    # bit-matrix goldens through the dict API (names, PanSN) incl. af on truncated names
+    gm = load_golden("bitmatrix.json")["matrices"][1]
+    n, W = gm["n"], gm["W"]
+    simm = oracle.identity(golden_counts(gm), W, 0)
+    nm = gm["names"]
+    dd = {(nm[i], nm[j]): float(simm[i, j]) for i in range(n) for j in range(i, n)}
+    for c in gm["kinds"]["match"]["pica2"]:
+        pi, ps = pica2.analyze_similarity_matrix(dict(dd), set(nm), len(dd), fh(c["threshold"]), c["L"], None, c["round"], ctx=ctx)
+        assert rel_close(pi, fh(c["pi"]), REL, 1e-300) and rel_close(ps, fh(c["pi_site"]), REL, 1e-300)
+    rows = [(a.split(":", 1)[0], b.split(":", 1)[0], v) for (a, b), v in dd.items()]
+    samples = sorted({a for a, _, _ in rows} | {b for _, b, _ in rows})
+    for c in gm["kinds"]["match"]["af"]:
+        cl = af.cluster(rows, samples, fh(c["threshold"]), ctx=ctx)
+        assert [sorted(x) for x in cl] == c["clusters"]
+
+
+def test_full_size_window_properties(ctx):
+    """BASELINE.json full size (465 haplotypes, 50 kb windows) — size-independent checks:
+    determinism, window-split additivity, pi bounds, Fst in range, per-site counts agree."""
+    import impop_amd
+    n, W = 465, 50000 * 40
+    bm = ctx.synthetic(n, W, seed=20251031)
+    inA = np.zeros(n, np.uint8); inA[:140] = 1
+    inB = np.zeros(n, np.uint8); inB[140:240] = 1
+    wins = impop_amd.fixed_windows(W, 50000)
+    a = bm.scan(wins, None, inA, inB)
+    b = bm.scan(wins, None, inA, inB, tile_blocks=16)
+    assert a.tobytes() == b.tobytes()  # bit-identical regardless of tiling
+    cnt = bm.site_counts(0, 50000)
+    assert int(((cnt > 0) & (cnt < n)).sum()) == int(a[0]["s_all"])
+    assert int((cnt.astype(np.int64) * (n - cnt.astype(np.int64))).sum()) == int(a[0]["sum_p"])
+    assert ((a["fst"] >= -1) & (a["fst"] <= 1)).all() and (a["pi"] > 0).all() and (a["pi"] < 0.5).all()
+    assert (a["tajima_d"] < 0).all()  # excess of rare variants by construction
+    bm.free()

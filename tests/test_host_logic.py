@@ -1,0 +1,115 @@
+"""CPU tests of the host layer: name handling, .sim ingest and its error texts, the C-ABI
+library loads and exports every declared symbol (no compute without a GPU)."""
+import io
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, load_golden
+
+
+def test_popnames_golden():
+    from impop_amd import popnames
+    g = load_golden("popnames.json")
+    assert [popnames.canonicalize_identifier(r) for r in g["raw"]] == g["canonical"]
+    exp, missing = popnames.expand_population(g["raw"], set(g["sequences"]))
+    assert sorted(exp) == g["expanded"] and missing == g["missing"]
+
+
+def test_abi_exports_every_declared_symbol():
+    from impop_amd import _lib
+    hdr = open(os.path.join(ROOT, "include", "impop_hip.h")).read()
+    declared = set(re.findall(r"^(?:int|const char \*)\s*\*?\s*(impop_[a-z0-9_]+)\(", hdr, flags=re.M))
+    assert len(declared) >= 28
+    lib = _lib.load()
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    out = subprocess.run(["nm", "-D", "--defined-only", _lib.SO_PATH], capture_output=True, text=True).stdout
+    exported = {l.split()[-1] for l in out.splitlines() if " T " in l}
+    assert declared <= exported
+    assert all(s.startswith("impop_") for s in exported if not s.startswith("_")), exported  # nothing else leaks
+    assert lib.impop_version() == 1
+
+
+def test_no_cpu_fallback_without_gpu():
+    import impop_amd
+    from impop_amd import _lib
+    import ctypes as C
+    c = C.c_int(-1)
+    rc = _lib.load().impop_device_count(C.byref(c))
+    if rc == 0 and c.value > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(impop_amd.ImpopError) as ei:
+        impop_amd.Context(0)
+    assert ei.value.code == _lib.E_NODEVICE and "no CPU fallback" in str(ei.value)
+    from impop_amd import runtime, tj_d
+    runtime.set_default_context(None)
+    with pytest.raises(impop_amd.ImpopError):
+        tj_d.tajimas_d(10, 5.0, 0.1)
+
+
+def test_product_never_imports_oracle():
+    bad = []
+    for base in ("impop_amd", "scripts"):
+        for dp, _, fs in os.walk(os.path.join(ROOT, base)):
+            for f in fs:
+                if f.endswith((".py", ".hip", ".h", ".cpp")):
+                    txt = open(os.path.join(dp, f)).read()
+                    if re.search(r"^\s*(from|import)\s+oracle\b", txt, flags=re.M) or "impop_oracle" in txt.replace("oracle/impop_oracle.c", ""):
+                        bad.append(os.path.join(dp, f))
+    assert not bad, bad
+
+
+def test_sim_ingest_and_error_texts(tmp_path, capsys):
+    from impop_amd import simfile
+    g = load_golden("cli_pansn.json")
+    p = tmp_path / "win8.sim"
+    p.write_text(g["sim_text"])
+    d, elements, pc = simfile.read_similarity_file_pica2(str(p))
+    assert pc == 64 and len(elements) == 8 and len(d) == 36
+    names = sorted(elements)
+    dense = simfile.densify(d, names)
+    assert dense.shape == (8, 8) and not np.isnan(dense).any() and (dense == dense.T).all()
+    d2, seqs = simfile.read_similarity_file_hfst(str(p))
+    assert d2 == d and seqs == elements
+    # error behaviour of pica2.read_similarity_file (messages on stdout, exit 1)
+    errs = g["errors"]
+    with pytest.raises(SystemExit) as e:
+        simfile.read_similarity_file_pica2(str(tmp_path / "nope.sim"))
+    assert e.value.code == 1
+    assert capsys.readouterr().out == f"Error: File not found {tmp_path / 'nope.sim'}\n"
+    bad = tmp_path / "bad.sim"
+    bad.write_text("a\tb\tc\nx\ty\t0.5\n")
+    with pytest.raises(SystemExit):
+        simfile.read_similarity_file_pica2(str(bad))
+    assert capsys.readouterr().out == errs[2]["stdout"]
+    bad2 = tmp_path / "bad2.sim"
+    bad2.write_text("group.a\tgroup.b\testimated.identity\nx\ty\tzzz\n")
+    with pytest.raises(SystemExit):
+        simfile.read_similarity_file_pica2(str(bad2))
+    assert capsys.readouterr().out == errs[3]["stdout"]
+    # h-fst flavour: bad float is warned and skipped, errors on stderr
+    d3, _ = simfile.read_similarity_file_hfst(str(bad2))
+    assert d3 == {} and "Warning: Invalid similarity value: zzz" in capsys.readouterr().err
+    with pytest.raises(SystemExit):
+        simfile.read_similarity_file_hfst(str(tmp_path / "nope.sim"))
+    assert capsys.readouterr().err == f"Error: File not found: {tmp_path / 'nope.sim'}\n"
+
+
+def test_window_helpers():
+    import impop_amd
+    w = impop_amd.fixed_windows(242_700_000, 50_000)
+    assert len(w) == 4854 and int(w[-1]["site_end"]) == 242_700_000 and (w["seq_len"] == 50_000).all()
+    s = impop_amd.fixed_windows(100_003, 10_000, 5_000)
+    assert int(s[0]["site_end"]) == 10_000 and int(s[1]["site_begin"]) == 5_000 and int(s[-1]["site_end"]) == 100_003
+    m = np.random.default_rng(0).integers(0, 2, size=(7, 130), dtype=np.uint8)
+    assert (impop_amd.unpack_hap_major(impop_amd.pack_hap_major(m), 130) == m).all()
+    mk = impop_amd.pack_mask(np.array([1, 0, 1] + [0] * 62 + [1]), 66)
+    assert mk.tolist() == [5, 2] and impop_amd.mask_from_indices([0, 2, 65], 66).tolist() == [5, 2]
+    mw = impop_amd.make_windows([(0, 10), (5, 20, 777)])
+    assert mw["seq_len"].tolist() == [10, 777]

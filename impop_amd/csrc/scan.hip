@@ -39,9 +39,28 @@ struct MaskArgs {
     uint32_t p[WPS], a[WPS], b[WPS];
 };
 
-struct u32x3 {
-    uint32_t x, y, z;
-};
+// Tuning knobs (defaults chosen by tools/tune_scan.py on MI355X)
+#ifndef IMPOP_SCAN_NT
+#define IMPOP_SCAN_NT 0        // 1: non-temporal (streaming) loads for the once-read matrix
+#endif
+#ifndef IMPOP_SCAN_UNROLL
+#define IMPOP_SCAN_UNROLL 2    // 64-site blocks in flight per wave
+#endif
+#ifndef IMPOP_SCAN_MIN_WAVES
+#define IMPOP_SCAN_MIN_WAVES 1 // __launch_bounds__ 2nd argument (waves per SIMD)
+#endif
+
+template <typename T>
+__device__ __forceinline__ T stream_load(const T *p) {
+#if IMPOP_SCAN_NT
+    return __builtin_nontemporal_load(p);
+#else
+    return *p;
+#endif
+}
+
+typedef uint32_t u32v4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32v2 __attribute__((ext_vector_type(2)));
 
 template <int WPS>
 __device__ __forceinline__ void load_site(const uint32_t *__restrict__ blk, uint32_t lane, uint32_t (&w)[WPS]) {
@@ -49,21 +68,23 @@ __device__ __forceinline__ void load_site(const uint32_t *__restrict__ blk, uint
     constexpr int R = WPS - 4 * (G - 1);
 #pragma unroll
     for (int g = 0; g < G - 1; ++g) {
-        const uint4 v = *reinterpret_cast<const uint4 *>(blk + g * 256 + lane * 4);
+        const u32v4 v = stream_load(reinterpret_cast<const u32v4 *>(blk + g * 256 + lane * 4));
         w[4 * g + 0] = v.x; w[4 * g + 1] = v.y; w[4 * g + 2] = v.z; w[4 * g + 3] = v.w;
     }
     const uint32_t *last = blk + (G - 1) * 256 + lane * R;
     if constexpr (R == 4) {
-        const uint4 v = *reinterpret_cast<const uint4 *>(last);
+        const u32v4 v = stream_load(reinterpret_cast<const u32v4 *>(last));
         w[4 * (G - 1) + 0] = v.x; w[4 * (G - 1) + 1] = v.y; w[4 * (G - 1) + 2] = v.z; w[4 * (G - 1) + 3] = v.w;
     } else if constexpr (R == 3) {
-        const u32x3 v = *reinterpret_cast<const u32x3 *>(last);
-        w[4 * (G - 1) + 0] = v.x; w[4 * (G - 1) + 1] = v.y; w[4 * (G - 1) + 2] = v.z;
+        // 12-byte, 4-byte-aligned: three dwords (the backend merges them into one dwordx3)
+        w[4 * (G - 1) + 0] = stream_load(last);
+        w[4 * (G - 1) + 1] = stream_load(last + 1);
+        w[4 * (G - 1) + 2] = stream_load(last + 2);
     } else if constexpr (R == 2) {
-        const uint2 v = *reinterpret_cast<const uint2 *>(last);
+        const u32v2 v = stream_load(reinterpret_cast<const u32v2 *>(last));
         w[4 * (G - 1) + 0] = v.x; w[4 * (G - 1) + 1] = v.y;
     } else {
-        w[4 * (G - 1)] = *last;
+        w[4 * (G - 1)] = stream_load(last);
     }
 }
 
@@ -125,25 +146,29 @@ __device__ __forceinline__ void tile_reduce_store(LaneAcc &acc, TilePartial *out
 }
 
 template <int WPS, bool SUBSET_P>
-__global__ __launch_bounds__(256) void scan_tiles_kernel(const uint32_t *__restrict__ sb,
-                                                         const ScanTile *__restrict__ tiles, const MaskArgs<WPS> mk,
-                                                         const PopSizes ps, TilePartial *__restrict__ out) {
+__global__ __launch_bounds__(256, IMPOP_SCAN_MIN_WAVES) void scan_tiles_kernel(const uint32_t *__restrict__ sb,
+                                                                               const ScanTile *__restrict__ tiles,
+                                                                               const MaskArgs<WPS> mk, const PopSizes ps,
+                                                                               TilePartial *__restrict__ out) {
     const ScanTile t = tiles[blockIdx.x];
     const uint64_t b0 = t.site_begin >> 6, b1 = (t.site_end + 63) >> 6;
     // wave index through readfirstlane: block addresses and the loop stay scalar (SGPR) state
     const uint32_t lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     LaneAcc acc;
     uint64_t b = b0 + wave;
-    // two blocks per iteration: 2*ceil(WPS/4) independent 1 KiB wave loads in flight per wave
-    for (; b + 4 < b1; b += 8) {
-        uint32_t w0[WPS], w1[WPS];
-        load_site<WPS>(sb + b * (64ull * WPS), lane, w0);
-        load_site<WPS>(sb + (b + 4) * (64ull * WPS), lane, w1);
-        const uint64_t s0 = b * 64 + lane, s1 = (b + 4) * 64 + lane;
-        site_accumulate<WPS, SUBSET_P>(w0, mk, ps, s0 >= t.site_begin && s0 < t.site_end, acc);
-        site_accumulate<WPS, SUBSET_P>(w1, mk, ps, s1 >= t.site_begin && s1 < t.site_end, acc);
+    constexpr int U = IMPOP_SCAN_UNROLL;
+    // U blocks per iteration: U*ceil(WPS/4) independent 1 KiB wave loads in flight per wave
+    for (; b + 4 * (U - 1) < b1; b += 4 * U) {
+        uint32_t w[U][WPS];
+#pragma unroll
+        for (int u = 0; u < U; ++u) load_site<WPS>(sb + (b + 4 * u) * (64ull * WPS), lane, w[u]);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint64_t s = (b + 4 * u) * 64 + lane;
+            site_accumulate<WPS, SUBSET_P>(w[u], mk, ps, s >= t.site_begin && s < t.site_end, acc);
+        }
     }
-    if (b < b1) {
+    for (; b < b1; b += 4) {
         uint32_t w0[WPS];
         load_site<WPS>(sb + b * (64ull * WPS), lane, w0);
         const uint64_t s0 = b * 64 + lane;

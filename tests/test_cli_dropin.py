@@ -1,0 +1,93 @@
+"""GPU: the drop-in CLIs (scripts/*.py) must print what the reference's CLIs printed for the
+same files (stdout/stderr/exit code captured by oracle/gen_golden.py from the real reference)."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT, fh, load_golden
+
+pytestmark = pytest.mark.gpu
+SCRIPTS = os.path.join(ROOT, "scripts")
+
+
+def run(script, argv, cwd):
+    return subprocess.run([sys.executable, os.path.join(SCRIPTS, script)] + argv, capture_output=True, text=True, cwd=cwd)
+
+
+def remap(argv, td):
+    """golden argv holds basenames for files that lived in the generator's temp dir"""
+    out = []
+    for a in argv[1:]:
+        if a.startswith("tmp") and not os.path.exists(os.path.join(td, a)):
+            out.append(td)  # the -d log dir
+        elif os.path.exists(os.path.join(td, a)):
+            out.append(os.path.join(td, a))
+        elif a.endswith(".sim") or a.endswith(".tsv"):
+            out.append(os.path.join(td, a))
+        else:
+            out.append(a)
+    return out
+
+
+def test_six_sequence_cli(tmp_path):
+    g = load_golden("six_seq.json")
+    td = str(tmp_path)
+    with open(os.path.join(td, "example_similarities.tsv"), "w") as f:
+        f.write("group.a\tgroup.b\testimated.identity\n")
+        for a, b, v in g["rows"]:
+            f.write(f"{a}\t{b}\t{fh(v)!r}\n")
+    open(os.path.join(td, "pop_A.txt"), "w").write("seq1_popA\nseq2_popA\nseq3_popA\n")
+    open(os.path.join(td, "pop_B.txt"), "w").write("seq4_popB\nseq5_popB\nseq6_popB\n")
+    for script, key in (("pica2.py", "pica2"), ("h-fst.py", "hfst"), ("tj_d.py", "tj_d"), ("af.py", "af")):
+        for c in g["cli"][key]:
+            r = run(script, remap(c["argv"], td), td)
+            assert r.returncode == c["rc"], (script, c["argv"], r.stderr)
+            if key == "tj_d":
+                # repr(float) text: allow the last digits to differ within 1e-12 relative
+                gl, wl = r.stdout.strip().splitlines(), c["stdout"].strip().splitlines()
+                assert len(gl) == len(wl)
+                for a, b in zip(gl, wl):
+                    if a != b:
+                        ta, tb = a.replace("=", " ").split(), b.replace("=", " ").split()
+                        assert len(ta) == len(tb)
+                        for x, y in zip(ta, tb):
+                            try:
+                                fx, fy = float(x), float(y)
+                            except ValueError:
+                                assert x == y
+                                continue
+                            assert (fx != fx and fy != fy) or abs(fx - fy) <= 1e-12 * max(abs(fx), abs(fy)), (a, b)
+            else:
+                assert r.stdout == c["stdout"], (script, c["argv"], r.stdout, c["stdout"], r.stderr)
+    assert os.path.exists(os.path.join(td, "example_similarities.log"))
+
+
+def test_pansn_cli(tmp_path):
+    g = load_golden("cli_pansn.json")
+    td = str(tmp_path)
+    open(os.path.join(td, "win8.sim"), "w").write(g["sim_text"])
+    open(os.path.join(td, "popA.txt"), "w").write(g["popA"])
+    open(os.path.join(td, "popB.txt"), "w").write(g["popB"])
+    open(os.path.join(td, "bad.sim"), "w").write("a\tb\tc\nx\ty\t0.5\n")
+    open(os.path.join(td, "bad2.sim"), "w").write("group.a\tgroup.b\testimated.identity\nx\ty\tzzz\n")
+    for script, key in (("pica2.py", "pica2"), ("h-fst.py", "hfst"), ("af.py", "af")):
+        for c in g[key]:
+            r = run(script, remap(c["argv"], td), td)
+            assert r.returncode == c["rc"], (script, c["argv"], r.stderr)
+            assert r.stdout == c["stdout"], (script, c["argv"], r.stdout, c["stdout"])
+            assert r.stderr == c["stderr"], (script, c["argv"], r.stderr, c["stderr"])
+    for c in g["errors"]:
+        script = c["argv"][0]
+        r = run(script, remap(c["argv"], td), td)
+        assert r.returncode == c["rc"] == 1
+        norm = lambda s: s.replace(td, "<TMP>")
+        want_out = c["stdout"]
+        # the golden stdout of pica2's "File not found" holds the generator's temp path
+        if "File not found" in want_out:
+            assert norm(r.stdout).startswith("Error: File not found <TMP>/nope.sim")
+        else:
+            assert r.stdout == want_out
+        assert norm(r.stderr) == c["stderr"]
+    assert os.path.exists(os.path.join(td, "win8.log")) and os.path.exists(os.path.join(td, "win8_fst.log"))

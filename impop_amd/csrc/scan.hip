@@ -40,14 +40,17 @@ struct MaskArgs {
 };
 
 // Tuning knobs (defaults chosen by tools/tune_scan.py on MI355X)
+// Measured (tools/tune_scan.py, 465 x 75 M sites, interleaved rounds): nt loads 6.65-6.68 TB/s
+// algorithmic vs 5.9-6.07 TB/s with default-policy loads (+10 %); unroll / occupancy / tile
+// size move the result by < 2 % once nt is on; a 64-VGPR cap (min_waves 8 at unroll 2) spills.
 #ifndef IMPOP_SCAN_NT
-#define IMPOP_SCAN_NT 0        // 1: non-temporal (streaming) loads for the once-read matrix
+#define IMPOP_SCAN_NT 1        // 1: non-temporal (streaming) loads for the once-read matrix
 #endif
 #ifndef IMPOP_SCAN_UNROLL
-#define IMPOP_SCAN_UNROLL 2    // 64-site blocks in flight per wave
+#define IMPOP_SCAN_UNROLL 0    // 64-site blocks in flight per wave; 0 = auto (about 8 wave loads in flight)
 #endif
 #ifndef IMPOP_SCAN_MIN_WAVES
-#define IMPOP_SCAN_MIN_WAVES 1 // __launch_bounds__ 2nd argument (waves per SIMD)
+#define IMPOP_SCAN_MIN_WAVES 6 // __launch_bounds__ 2nd argument (waves per SIMD)
 #endif
 
 template <typename T>
@@ -156,7 +159,8 @@ __global__ __launch_bounds__(256, IMPOP_SCAN_MIN_WAVES) void scan_tiles_kernel(c
     const uint32_t lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     LaneAcc acc;
     uint64_t b = b0 + wave;
-    constexpr int U = IMPOP_SCAN_UNROLL;
+    constexpr int G = (WPS + 3) / 4;
+    constexpr int U = IMPOP_SCAN_UNROLL > 0 ? IMPOP_SCAN_UNROLL : (G >= 3 ? 2 : G == 2 ? 4 : 8);
     // U blocks per iteration: U*ceil(WPS/4) independent 1 KiB wave loads in flight per wave
     for (; b + 4 * (U - 1) < b1; b += 4 * U) {
         uint32_t w[U][WPS];
@@ -362,7 +366,7 @@ IMPOP_API int impop_scan_plan_create(impop_ctx *ctx, const impop_matrix *m, cons
     }
     REQUIRE(prm.d_pi_mode >= 0 && prm.d_pi_mode <= 2, "impop_scan_params.d_pi_mode must be 0..2");
     REQUIRE(prm.s_scope == 0 || prm.s_scope == 1, "impop_scan_params.s_scope must be 0 or 1");
-    const uint32_t tile_blocks = prm.tile_blocks ? prm.tile_blocks : 64;
+    const uint32_t tile_blocks = prm.tile_blocks ? prm.tile_blocks : 32;
     REQUIRE(tile_blocks <= 4096, "impop_scan_params.tile_blocks too large");
     for (uint64_t i = 0; i < n_windows; ++i) {
         REQUIRE(windows[i].site_begin <= windows[i].site_end && windows[i].site_end <= m->g.n_site,

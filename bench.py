@@ -31,6 +31,26 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
+def pmc_traffic(n_hap, window, n_windows):
+    """HBM bytes per launch of the streaming kernel from the committed rocprofv3 PMC passes
+    (profiles/r01b_pmc_hbm_traffic.json: FETCH_SIZE x1024x2 + WRITE_SIZE x1024, collected in their
+    own runs as the microarch guide prescribes).  PMC cannot be read live inside this process;
+    the figure is reported only when it was collected on this exact workload, else null."""
+    path = os.path.join(ROOT, "profiles", "r01b_pmc_hbm_traffic.json")
+    try:
+        with open(path) as f:
+            d = json.load(f)
+    except OSError:
+        return None, None
+    wl = d.get("workload", {})
+    if (wl.get("n_hap"), wl.get("window_sites"), wl.get("windows_per_gpu")) != (n_hap, window, n_windows):
+        return None, None
+    for k, e in d["kernels"].items():
+        if "scan_tiles_kernel" in k:
+            return e["hbm_bytes_per_launch"], os.path.relpath(path, ROOT)
+    return None, None
+
+
 def cpu_baseline(bm, windows, in_a, in_b, budget_s=12.0):
     """Time the CPU oracle (oracle/impop_oracle.c, the restated reference algorithm: all-pairs
     Hamming -> identity -> pica2/h-fst/tj_d) on a bounded sample of the SAME windows, one host
@@ -191,6 +211,7 @@ def main():
         algo_bytes = n * n_site / 8.0                      # n*W/8 per window x windows per launch
         avg_kern_s = (kern_ms / 1e3) / max(launches, 1)
         achieved = algo_bytes / avg_kern_s / 1e9
+        traffic, traffic_src = pmc_traffic(n, W, NW)
         out = {
             "metric": "windows/sec (pi+Fst+D) for 465-hap HPRC, 50 kb windows",
             "value": value, "unit": "windows/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -202,7 +223,7 @@ def main():
                        "layout": "SB64 site-blocked wave-interleaved bit matrix", "tiles": plan.n_tiles,
                        "parallelism": f"windows sharded over {world} GPU(s), one all_gather of records per step"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": "scan_tiles_kernel<15,false>", "kernel_ms_avg": avg_kern_s * 1e3,
                          "algorithmic_bytes_per_launch": algo_bytes, "layout_bytes_per_launch": plan.bytes_streamed,
                          "layout_GBps": plan.bytes_streamed / avg_kern_s / 1e9},

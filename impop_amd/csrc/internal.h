@@ -72,7 +72,7 @@ struct impop_matrix {
     uint64_t sb_bytes = 0;
     uint32_t *d_hm = nullptr;   // hap-major: n_hap_pad rows x hm_stride dwords (optional)
     uint64_t hm_stride = 0;     // dwords per row (multiple of 4), covers n_block*64 sites
-    uint32_t n_hap_pad = 0;     // rows padded to a multiple of 64 (zero rows)
+    uint32_t n_hap_pad = 0;     // rows padded to a multiple of 128 (zero rows)
     uint64_t hm_bytes = 0;
     int device = 0;
 };

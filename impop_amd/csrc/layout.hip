@@ -100,7 +100,7 @@ int launch_hm_to_sb(impop_ctx *ctx, const uint32_t *d_hm, uint64_t hm_stride, co
     if (g.n_block == 0) return IMPOP_OK;
     const uint64_t grid = (g.n_block + 3) / 4;
     REQUIRE(grid < 0x7FFFFFFFull, "matrix too long for one launch (%llu blocks)", (unsigned long long)g.n_block);
-    const uint32_t n_rows = (g.n_hap + 63) / 64 * 64;
+    const uint32_t n_rows = (g.n_hap + 127) / 128 * 128;
     hipLaunchKernelGGL(hm_to_sb_kernel, dim3((uint32_t)grid), dim3(256), 0, ctx->stream, d_hm, hm_stride, n_rows, g.wps,
                        g.G, g.r, g.n_block, d_sb);
     HIP_TRY(hipGetLastError());
@@ -159,7 +159,7 @@ static int alloc_matrix(impop_ctx *ctx, uint32_t n_hap, uint64_t n_site, bool wa
     impop_matrix *m = new impop_matrix();
     m->g = make_geom(n_hap, n_site);
     m->device = ctx->device;
-    m->n_hap_pad = (n_hap + 63) / 64 * 64;
+    m->n_hap_pad = (n_hap + 127) / 128 * 128;  // Gram tiles are 128 haplotypes wide
     m->sb_bytes = m->g.n_block * 64ull * m->g.wps * 4ull;
     // one extra block of slack so software-pipelined kernels may prefetch one block past the end
     hipError_t e = hipMalloc((void **)&m->d_sb, m->sb_bytes + 64ull * m->g.wps * 4ull + 256);

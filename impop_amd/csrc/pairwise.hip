@@ -2,91 +2,135 @@
 // window, then the full pica2 / h-fst semantics (thresholds, rounding,
 // greedy grouping) on identities formed on the fly from the integer Gram matrix.
 //
-// v1 Gram kernel: 64x64 haplotype tile per 256-thread workgroup, upper-triangular tile grid,
-// hap-major rows staged through LDS in 32-dword (1024-site) K-chunks, 4x4 register tile per
-// thread with AND + v_bcnt accumulate.  Rows/cols are assigned with stride 16 so that the LDS
-// reads are conflict-free at row pitch 33 dwords.  This path is VALU-bound, not HBM-bound
-// (SURVEY.md §8d): its roof is the popcount issue rate, reported separately from the scan.
+// This path is VALU-bound, not HBM-bound: its roof is the popcount issue rate
+// (2 lane-ops per haplotype pair per 32 sites), reported separately from the scan.
 #include <vector>
 
 #include "stats_kernels.h"
 
 namespace impop {
 
-constexpr int KC = 32;      // dwords per K-chunk
-constexpr int PITCH = 33;   // LDS row pitch (dwords)
+// ---- Gram kernel v2 ---------------------------------------------------------------------
+// 128 x 128 haplotype tile per 256-thread workgroup (upper-triangular tile grid x windows);
+// thread (ty, tx) owns the 8 x 8 outputs rows {ty+16r} x cols {tx+16c}.  The site axis is
+// consumed in 16-dword (512-site) chunks staged through LDS with row pitch 20 dwords: the
+// 16 distinct rows a wave touches per ds_read_b128 then start on distinct 4-bank groups
+// (tx*20 mod 64 = 0,20,40,60,16,...: all different multiples of 4) => conflict-free.  Per
+// chunk a thread issues 4x16 ds_read_b128 for 8*8*16 AND+BCNT pairs (1:32 LDS:VALU), so the
+// kernel is bound by the VALU popcount rate.  Global->LDS staging is double-buffered through
+// registers (loads for chunk t+1 are issued before the math of chunk t).  Diagonal tiles skip
+// the r > c sub-blocks (strictly below the diagonal for every thread), 28 of 64.
+constexpr int GT = 128;      // tile edge (haplotypes)
+constexpr int KC = 16;       // dwords per K-chunk
+constexpr int PITCH = 20;    // LDS row pitch (dwords)
 
 struct GramWindow {
     uint64_t site_begin, site_end;
 };
 
-__global__ __launch_bounds__(256) void gram_kernel(const uint32_t *__restrict__ hm, uint64_t hm_stride, uint32_t n_tiles,
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+template <bool DIAG>
+__device__ __forceinline__ void gram_chunk_math(const uint32_t *__restrict__ As, const uint32_t *__restrict__ Bs,
+                                                uint32_t ty, uint32_t tx, int32_t (&acc)[8][8]) {
+#pragma unroll 1
+    for (int k4 = 0; k4 < KC / 4; ++k4) {
+        u32x4 a[8], b[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) a[r] = *reinterpret_cast<const u32x4 *>(As + (ty + 16 * r) * PITCH + 4 * k4);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) b[c] = *reinterpret_cast<const u32x4 *>(Bs + (tx + 16 * c) * PITCH + 4 * k4);
+#pragma unroll
+        for (int r = 0; r < 8; ++r)
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                if (DIAG && r > c) continue;
+                acc[r][c] += __popc(a[r].x & b[c].x) + __popc(a[r].y & b[c].y) + __popc(a[r].z & b[c].z) +
+                             __popc(a[r].w & b[c].w);
+            }
+    }
+}
+
+__global__ __launch_bounds__(256, 2) void gram_kernel(const uint32_t *__restrict__ hm, uint64_t hm_stride, uint32_t n_tiles,
                                                    const GramWindow *__restrict__ wins, int32_t *__restrict__ out,
                                                    uint32_t ld, uint64_t out_stride) {
-    __shared__ uint32_t As[64 * PITCH];
-    __shared__ uint32_t Bs[64 * PITCH];
+    __shared__ __attribute__((aligned(16))) uint32_t lds[2][2][GT * PITCH];  // [buffer][A|B]
     // decode upper-triangular tile pair (ti <= tj) from blockIdx.x
     uint32_t rem = blockIdx.x, ti = 0;
     while (rem >= n_tiles - ti) { rem -= n_tiles - ti; ++ti; }
     const uint32_t tj = ti + rem;
+    const bool diag = ti == tj;
     const GramWindow w = wins[blockIdx.y];
     const uint32_t tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
-    int32_t acc[4][4];
+    int32_t acc[8][8];
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
+    for (int r = 0; r < 8; ++r)
 #pragma unroll
-        for (int c = 0; c < 4; ++c) acc[r][c] = 0;
+        for (int c = 0; c < 8; ++c) acc[r][c] = 0;
     if (w.site_end > w.site_begin) {
-        const uint64_t d0 = w.site_begin >> 5, d1 = (w.site_end + 31) >> 5;  // dword range
+        const uint64_t d0 = w.site_begin >> 5, d1 = (w.site_end + 31) >> 5;  // dword range of the window
+        const uint64_t c0 = d0 & ~3ull;                                        // 16-byte aligned start
         const uint32_t first_mask = 0xFFFFFFFFu << (w.site_begin & 31);
         const uint32_t last_mask = (w.site_end & 31) ? (0xFFFFFFFFu >> (32 - (w.site_end & 31))) : 0xFFFFFFFFu;
-        const uint32_t *rowA = hm + (uint64_t)(ti * 64) * hm_stride;
-        const uint32_t *rowB = hm + (uint64_t)(tj * 64) * hm_stride;
-        for (uint64_t dk = d0; dk < d1; dk += KC) {
-            // stage 64 rows x KC dwords of both tiles (coalesced along the site axis)
-#pragma unroll
-            for (int i = 0; i < (64 * KC) / 256; ++i) {
-                const uint32_t e = tid + 256 * i, row = e / KC, col = e % KC;
-                const uint64_t d = dk + col;
-                uint32_t va = 0, vb = 0;
-                if (d < d1) {
-                    uint32_t m = 0xFFFFFFFFu;
-                    if (d == d0) m &= first_mask;
-                    if (d == d1 - 1) m &= last_mask;
-                    va = rowA[(uint64_t)row * hm_stride + d] & m;  // masking one operand suffices for AND
-                    vb = rowB[(uint64_t)row * hm_stride + d];
-                }
-                As[row * PITCH + col] = va;
-                Bs[row * PITCH + col] = vb;
-            }
+        // staging map: 128 rows x 4 uint4 per tile = 512 uint4; thread t moves uint4 #t and #t+256
+        const uint32_t srow = tid >> 2, scol = (tid & 3) * 4;  // rows srow and srow+64
+        const uint32_t *gA = hm + (uint64_t)(ti * GT + srow) * hm_stride + scol;
+        const uint32_t *gB = hm + (uint64_t)(tj * GT + srow) * hm_stride + scol;
+        const uint64_t row64 = 64 * hm_stride;
+        auto mask_of = [&](uint64_t d) -> uint32_t {
+            uint32_t m = (d >= d0 && d < d1) ? 0xFFFFFFFFu : 0u;
+            if (d == d0) m &= first_mask;
+            if (d == d1 - 1) m &= last_mask;
+            return m;
+        };
+        u32x4 ra0, ra1, rb0, rb1;
+        auto fetch = [&](uint64_t dk) {
+            // rows are padded to a multiple of 4 dwords and cover every block of the matrix, so a
+            // 16-byte load at an aligned dword < hm_stride is always in bounds
+            const bool in = dk + scol < hm_stride;
+            const u32x4 z = {0u, 0u, 0u, 0u};
+            ra0 = in ? *reinterpret_cast<const u32x4 *>(gA + dk) : z;
+            ra1 = in ? *reinterpret_cast<const u32x4 *>(gA + row64 + dk) : z;
+            rb0 = in ? *reinterpret_cast<const u32x4 *>(gB + dk) : z;
+            rb1 = in ? *reinterpret_cast<const u32x4 *>(gB + row64 + dk) : z;
+            const uint64_t d = dk + scol;
+            const u32x4 m = {mask_of(d), mask_of(d + 1), mask_of(d + 2), mask_of(d + 3)};
+            ra0 &= m; ra1 &= m;  // masking one operand suffices for AND
+        };
+        auto stash = [&](int buf) {
+            *reinterpret_cast<u32x4 *>(&lds[buf][0][srow * PITCH + scol]) = ra0;
+            *reinterpret_cast<u32x4 *>(&lds[buf][0][(srow + 64) * PITCH + scol]) = ra1;
+            *reinterpret_cast<u32x4 *>(&lds[buf][1][srow * PITCH + scol]) = rb0;
+            *reinterpret_cast<u32x4 *>(&lds[buf][1][(srow + 64) * PITCH + scol]) = rb1;
+        };
+        fetch(c0);
+        stash(0);
+        __syncthreads();
+        int buf = 0;
+        for (uint64_t dk = c0; dk < d1; dk += KC) {
+            const bool more = dk + KC < d1;
+            if (more) fetch(dk + KC);
+            if (diag) gram_chunk_math<true>(lds[buf][0], lds[buf][1], ty, tx, acc);
+            else gram_chunk_math<false>(lds[buf][0], lds[buf][1], ty, tx, acc);
+            if (more) stash(buf ^ 1);
             __syncthreads();
-#pragma unroll 8
-            for (int k = 0; k < KC; ++k) {
-                uint32_t a[4], b[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) a[r] = As[(ty + 16 * r) * PITCH + k];
-#pragma unroll
-                for (int c = 0; c < 4; ++c) b[c] = Bs[(tx + 16 * c) * PITCH + k];
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) acc[r][c] += __popc(a[r] & b[c]);
-            }
-            __syncthreads();
+            buf ^= 1;
         }
     }
     int32_t *o = out + (uint64_t)blockIdx.y * out_stride;
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
+    for (int r = 0; r < 8; ++r)
 #pragma unroll
-        for (int c = 0; c < 4; ++c)
-            o[(uint64_t)(ti * 64 + ty + 16 * r) * ld + (tj * 64 + tx + 16 * c)] = acc[r][c];
+        for (int c = 0; c < 8; ++c) {
+            if (diag && r > c) continue;  // lower half of a diagonal tile: filled by symmetry on export
+            o[(uint64_t)(ti * GT + ty + 16 * r) * ld + (tj * GT + tx + 16 * c)] = acc[r][c];
+        }
 }
 
 // mirror the upper tiles into the lower triangle (only for host export)
 __global__ void gram_symmetrize_kernel(int32_t *g, uint32_t ld) {
     const uint32_t i = blockIdx.y * blockDim.y + threadIdx.y, j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < ld && j < ld && (i / 64) > (j / 64)) g[(uint64_t)i * ld + j] = g[(uint64_t)j * ld + i];
+    if (i < ld && j < ld && i > j) g[(uint64_t)i * ld + j] = g[(uint64_t)j * ld + i];
 }
 
 __global__ void identity_dense_kernel(SimBatch b, uint32_t n, double *__restrict__ out) {
@@ -124,7 +168,7 @@ __global__ void pairwise_finalize_kernel(PairFinalIn in, uint64_t n_windows, uin
 }
 
 static int launch_gram(impop_ctx *ctx, const impop_matrix *m, const GramWindow *d_wins, uint32_t n_win, int32_t *d_out) {
-    const uint32_t T = m->n_hap_pad / 64;
+    const uint32_t T = m->n_hap_pad / GT;
     const uint32_t pairs = T * (T + 1) / 2;
     REQUIRE(n_win <= 65535, "gram: at most 65535 windows per launch");
     hipLaunchKernelGGL(gram_kernel, dim3(pairs, n_win), dim3(256), 0, ctx->stream, m->d_hm, m->hm_stride, T, d_wins, d_out,

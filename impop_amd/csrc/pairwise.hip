@@ -127,6 +127,142 @@ __global__ __launch_bounds__(256, 2) void gram_kernel(const uint32_t *__restrict
         }
 }
 
+// ---- Gram kernel v3: int8 MFMA ----------------------------------------------------------------
+// G[i][j] = sum_s x_i[s] x_j[s] as a dense contraction on the matrix cores: bits are expanded to
+// 0/1 bytes in LDS and multiplied with v_mfma_i32_32x32x32_i8 (exact: int32 accumulation).
+// Measured motivation (tools/micro/valu_rate.hip): v_bcnt_u32_b32 is a half-rate instruction on
+// gfx950 (4.8 vs 2.55 cycles per wave-instruction for v_and), so the VALU popcount form tops out
+// near 1e5 windows/s at n = 465, W = 50 000, while int8 MFMA has ~10x the raw MAC rate.
+//
+// Workgroup = 128 x 128 haplotype tile, 4 waves as 2 x 2, each wave 2 x 2 MFMA tiles of 32 x 32.
+// The site axis is consumed in 512-site super-chunks (16 dwords per row, prefetched one ahead in
+// registers); thread (r = tid/2, h = tid%2) owns dwords 8h..8h+7 of row r of BOTH operand tiles.
+// A sub-chunk (K = 64) takes dword j of h = 0 and dword j of h = 1: the sites inside a sub-chunk
+// are not contiguous, which is irrelevant for a sum over sites, and it keeps every lane busy in
+// the expansion.  Byte rows in LDS have pitch 80 B so that ds_read_b128 fragment reads of 16
+// consecutive rows start in distinct 16-byte bank groups.  Both MFMA operands use the same
+// (lane>>5, byte) -> site mapping, so the result does not depend on the instruction's internal
+// k order; the C/D map is the documented col = lane&31, row = (reg&3) + 8(reg>>2) + 4(lane>>5).
+constexpr int BP = 80;  // LDS byte-row pitch
+
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x16 __attribute__((ext_vector_type(16)));
+
+// 4 bits -> 4 bytes of 0/1: (nibble * 0x204081) & 0x01010101 (bit i lands on bit 8i)
+__device__ __forceinline__ uint32_t expand_nibble(uint32_t x, int i) {
+    return __umul24((x >> (4 * i)) & 0xFFu, 0x204081u) & 0x01010101u;  // bits 4..7 of the byte land off the kept positions
+}
+__device__ __forceinline__ void expand_dword_to_lds(uint32_t x, unsigned char *dst /*32 bytes, 16-B aligned*/) {
+    u32x4 lo = {expand_nibble(x, 0), expand_nibble(x, 1), expand_nibble(x, 2), expand_nibble(x, 3)};
+    u32x4 hi = {expand_nibble(x, 4), expand_nibble(x, 5), expand_nibble(x, 6), expand_nibble(x, 7)};
+    *reinterpret_cast<u32x4 *>(dst) = lo;
+    *reinterpret_cast<u32x4 *>(dst + 16) = hi;
+}
+
+__global__ __launch_bounds__(256, 2) void gram_mfma_kernel(const uint32_t *__restrict__ hm, uint64_t hm_stride,
+                                                           uint32_t n_tiles, const GramWindow *__restrict__ wins,
+                                                           int32_t *__restrict__ out, uint32_t ld, uint64_t out_stride) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2][2][GT * BP];  // [buffer][A|B] byte tiles, 40 KB
+    uint32_t rem = blockIdx.x, ti = 0;
+    while (rem >= n_tiles - ti) { rem -= n_tiles - ti; ++ti; }
+    const uint32_t tj = ti + rem;
+    const bool diag = ti == tj;
+    const GramWindow w = wins[blockIdx.y];
+    const uint32_t tid = threadIdx.x, lane = tid & 63;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6), wr = wave >> 1, wc = wave & 1;
+    const bool wave_active = !(diag && wr == 1 && wc == 0);  // strictly below the diagonal: nothing to compute
+    i32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[a][b][e] = 0;
+    if (w.site_end > w.site_begin) {
+        const uint64_t d0 = w.site_begin >> 5, d1 = (w.site_end + 31) >> 5;
+        const uint64_t c0 = d0 & ~3ull;
+        const uint32_t first_mask = 0xFFFFFFFFu << (w.site_begin & 31);
+        const uint32_t last_mask = (w.site_end & 31) ? (0xFFFFFFFFu >> (32 - (w.site_end & 31))) : 0xFFFFFFFFu;
+        const uint32_t r = tid >> 1, h = tid & 1;
+        const uint32_t *gA = hm + (uint64_t)(ti * GT + r) * hm_stride + 8 * h;
+        const uint32_t *gB = hm + (uint64_t)(tj * GT + r) * hm_stride + 8 * h;
+        auto mask_of = [&](uint64_t d) -> uint32_t {
+            uint32_t m = (d >= d0 && d < d1) ? 0xFFFFFFFFu : 0u;
+            if (d == d0) m &= first_mask;
+            if (d == d1 - 1) m &= last_mask;
+            return m;
+        };
+        u32x4 ca0, ca1, cb0, cb1, na0, na1, nb0, nb1;  // current / next super-chunk: 8 dwords of A and of B
+        auto fetch = [&](uint64_t dk) {
+            const u32x4 z = {0u, 0u, 0u, 0u};
+            const uint64_t d = dk + 8 * h;
+            const bool in0 = d < hm_stride, in1 = d + 4 < hm_stride;
+            na0 = in0 ? *reinterpret_cast<const u32x4 *>(gA + dk) : z;
+            na1 = in1 ? *reinterpret_cast<const u32x4 *>(gA + dk + 4) : z;
+            nb0 = in0 ? *reinterpret_cast<const u32x4 *>(gB + dk) : z;
+            nb1 = in1 ? *reinterpret_cast<const u32x4 *>(gB + dk + 4) : z;
+            const u32x4 m0 = {mask_of(d), mask_of(d + 1), mask_of(d + 2), mask_of(d + 3)};
+            const u32x4 m1 = {mask_of(d + 4), mask_of(d + 5), mask_of(d + 6), mask_of(d + 7)};
+            na0 &= m0; na1 &= m1;  // a masked A byte is 0 => the product is 0
+        };
+        unsigned char *const wrA = &lds[0][0][r * BP + 32 * h], *const wrB = &lds[0][1][r * BP + 32 * h];
+        constexpr int BUF = 2 * GT * BP;  // bytes between the two buffers
+        const uint32_t frag_off = (lane & 31) * BP + 16 * (lane >> 5);
+        fetch(c0);
+        for (uint64_t dk = c0; dk < d1; dk += 16) {
+            ca0 = na0; ca1 = na1; cb0 = nb0; cb1 = nb1;
+            if (dk + 16 < d1) fetch(dk + 16);
+            // sub-chunk 0 of this super-chunk
+            expand_dword_to_lds(ca0.x, wrA);
+            expand_dword_to_lds(cb0.x, wrB);
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int buf = j & 1;
+                if (j < 7) {  // expand sub-chunk j+1 into the other buffer while this one feeds the MFMAs
+                    const uint32_t xa = (j + 1) < 4 ? ca0[(j + 1) & 3] : ca1[(j + 1) & 3];
+                    const uint32_t xb = (j + 1) < 4 ? cb0[(j + 1) & 3] : cb1[(j + 1) & 3];
+                    expand_dword_to_lds(xa, wrA + (buf ^ 1) * BUF);
+                    expand_dword_to_lds(xb, wrB + (buf ^ 1) * BUF);
+                }
+                if (wave_active) {
+                    const unsigned char *pa = &lds[buf][0][(64 * wr) * BP + frag_off];
+                    const unsigned char *pb = &lds[buf][1][(64 * wc) * BP + frag_off];
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks) {
+                        const i32x4 a0 = *reinterpret_cast<const i32x4 *>(pa + 32 * ks);
+                        const i32x4 a1 = *reinterpret_cast<const i32x4 *>(pa + 32 * BP + 32 * ks);
+                        const i32x4 b0 = *reinterpret_cast<const i32x4 *>(pb + 32 * ks);
+                        const i32x4 b1 = *reinterpret_cast<const i32x4 *>(pb + 32 * BP + 32 * ks);
+                        acc[0][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, b0, acc[0][0], 0, 0, 0);
+                        acc[0][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, b1, acc[0][1], 0, 0, 0);
+                        acc[1][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, b0, acc[1][0], 0, 0, 0);
+                        acc[1][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, b1, acc[1][1], 0, 0, 0);
+                    }
+                }
+                __syncthreads();
+            }
+        }
+    }
+    if (wave_active) {
+        int32_t *o = out + (uint64_t)blockIdx.y * out_stride;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const uint32_t row = ti * GT + 64 * wr + 32 * mt + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+                    const uint32_t col = tj * GT + 64 * wc + 32 * nt + (lane & 31);
+                    o[(uint64_t)row * ld + col] = acc[mt][nt][e];
+                }
+    }
+}
+
+#ifndef IMPOP_GRAM_MFMA
+#define IMPOP_GRAM_MFMA 1  // 0: VALU AND+BCNT kernel (kept for A/B measurements)
+#endif
+
 // mirror the upper tiles into the lower triangle (only for host export)
 __global__ void gram_symmetrize_kernel(int32_t *g, uint32_t ld) {
     const uint32_t i = blockIdx.y * blockDim.y + threadIdx.y, j = blockIdx.x * blockDim.x + threadIdx.x;
@@ -171,8 +307,13 @@ static int launch_gram(impop_ctx *ctx, const impop_matrix *m, const GramWindow *
     const uint32_t T = m->n_hap_pad / GT;
     const uint32_t pairs = T * (T + 1) / 2;
     REQUIRE(n_win <= 65535, "gram: at most 65535 windows per launch");
+#if IMPOP_GRAM_MFMA
+    hipLaunchKernelGGL(gram_mfma_kernel, dim3(pairs, n_win), dim3(256), 0, ctx->stream, m->d_hm, m->hm_stride, T, d_wins,
+                       d_out, m->n_hap_pad, (uint64_t)m->n_hap_pad * m->n_hap_pad);
+#else
     hipLaunchKernelGGL(gram_kernel, dim3(pairs, n_win), dim3(256), 0, ctx->stream, m->d_hm, m->hm_stride, T, d_wins, d_out,
                        m->n_hap_pad, (uint64_t)m->n_hap_pad * m->n_hap_pad);
+#endif
     HIP_TRY(hipGetLastError());
     return IMPOP_OK;
 }

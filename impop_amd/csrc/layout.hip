@@ -2,6 +2,8 @@
 // device (wave64 readlane / ballot bit transposes), the synthetic generator and download.
 #include <string.h>
 
+#include <algorithm>
+
 #include <vector>
 
 #include "device_utils.h"
@@ -61,7 +63,7 @@ __global__ __launch_bounds__(256) void hm_to_sb_kernel(const uint32_t *__restric
 __global__ __launch_bounds__(256) void sb_to_hm_kernel(const uint32_t *__restrict__ sb, uint32_t wps, uint32_t G,
                                                        uint32_t r, uint64_t blk_begin, uint64_t blk_end,
                                                        uint32_t *__restrict__ hm, uint64_t hm_stride,
-                                                       uint32_t n_rows) {
+                                                       uint32_t n_rows, uint64_t rb_nq) {
     const uint32_t lane = threadIdx.x & 63;
     const uint64_t b = blk_begin + (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (b >= blk_end) return;  // wave-uniform
@@ -75,7 +77,9 @@ __global__ __launch_bounds__(256) void sb_to_hm_kernel(const uint32_t *__restric
         }
         const uint32_t row = 32 * k + lane;
         if (lane < 32 && row < n_rows) {
-            uint32_t *p = hm + (uint64_t)row * hm_stride + 2 * (b - blk_begin);
+            const uint64_t d = 2 * (b - blk_begin);  // first of the two dwords of this 64-site block
+            uint32_t *p = rb_nq ? hm + ((((uint64_t)(row >> 5) * rb_nq + (d >> 2)) * 32 + (row & 31)) * 4 + (d & 3))
+                                : hm + (uint64_t)row * hm_stride + d;
             p[0] = (uint32_t)keep;
             p[1] = (uint32_t)(keep >> 32);
         }
@@ -108,12 +112,12 @@ int launch_hm_to_sb(impop_ctx *ctx, const uint32_t *d_hm, uint64_t hm_stride, co
 }
 
 int launch_sb_to_hm(impop_ctx *ctx, const uint32_t *d_sb, const SbGeom &g, uint64_t blk_begin, uint64_t blk_end,
-                    uint32_t *d_hm, uint64_t hm_stride, uint32_t n_rows) {
+                    uint32_t *d_hm, uint64_t hm_stride, uint32_t n_rows, uint64_t rb_nq) {
     if (blk_end <= blk_begin) return IMPOP_OK;
     const uint64_t grid = (blk_end - blk_begin + 3) / 4;
     REQUIRE(grid < 0x7FFFFFFFull, "range too long for one launch");
     hipLaunchKernelGGL(sb_to_hm_kernel, dim3((uint32_t)grid), dim3(256), 0, ctx->stream, d_sb, g.wps, g.G, g.r, blk_begin,
-                       blk_end, d_hm, hm_stride, n_rows);
+                       blk_end, d_hm, hm_stride, n_rows, rb_nq);
     HIP_TRY(hipGetLastError());
     return IMPOP_OK;
 }
@@ -174,14 +178,20 @@ static int alloc_matrix(impop_ctx *ctx, uint32_t n_hap, uint64_t n_site, bool wa
         return hip_fail(e, "hipMemsetAsync", __FILE__, __LINE__);
     }
     if (want_hm) {
-        m->hm_stride = (m->g.n_block * 2 + 3) / 4 * 4;
-        if (m->hm_stride == 0) m->hm_stride = 4;
-        m->hm_bytes = (uint64_t)m->n_hap_pad * m->hm_stride * 4ull;
-        e = hipMalloc((void **)&m->d_hm, m->hm_bytes);
+        m->rb_nq = (m->g.n_block * 2 + 3) / 4 + 1;  // quads per row + one quad of prefetch slack
+        m->rb_bytes = (uint64_t)(m->n_hap_pad / 32) * m->rb_nq * 32ull * 16ull;
+        e = hipMalloc((void **)&m->d_rb, m->rb_bytes);
         if (e != hipSuccess) {
             hipFree(m->d_sb);
             delete m;
-            return hip_fail(e, "hipMalloc(hap-major matrix)", __FILE__, __LINE__);
+            return hip_fail(e, "hipMalloc(row-group-blocked matrix)", __FILE__, __LINE__);
+        }
+        e = hipMemsetAsync(m->d_rb, 0, m->rb_bytes, ctx->stream);
+        if (e != hipSuccess) {
+            hipFree(m->d_sb);
+            hipFree(m->d_rb);
+            delete m;
+            return hip_fail(e, "hipMemsetAsync", __FILE__, __LINE__);
         }
     }
     *out = m;
@@ -204,31 +214,39 @@ IMPOP_API int impop_matrix_upload(impop_ctx *ctx, const uint64_t *bits, uint32_t
             (unsigned long long)row_stride_words, (unsigned long long)words);
     HIP_TRY(hipSetDevice(ctx->device));
     impop_matrix *m = nullptr;
-    int rc = alloc_matrix(ctx, n_hap, n_site, true, &m);
+    const bool want_rb = (keep_flags & IMPOP_KEEP_HAP_MAJOR) != 0;
+    int rc = alloc_matrix(ctx, n_hap, n_site, want_rb, &m);
     if (rc) return rc;
+    // transient plain hap-major staging copy of the caller's rows (freed before returning)
+    const uint64_t hm_stride = std::max<uint64_t>((m->g.n_block * 2 + 3) / 4 * 4, 4);
+    const uint64_t hm_bytes = (uint64_t)m->n_hap_pad * hm_stride * 4ull;
+    uint32_t *d_hm = nullptr;
     auto fail = [&](int code) {
+        if (d_hm) hipFree(d_hm);
         impop_matrix_free(ctx, m);
         return code;
     };
-    hipError_t e = hipMemsetAsync(m->d_hm, 0, m->hm_bytes, ctx->stream);
+    hipError_t e = hipMalloc((void **)&d_hm, hm_bytes);
+    if (e != hipSuccess) return fail(hip_fail(e, "hipMalloc(upload staging)", __FILE__, __LINE__));
+    e = hipMemsetAsync(d_hm, 0, hm_bytes, ctx->stream);
     if (e != hipSuccess) return fail(hip_fail(e, "hipMemsetAsync", __FILE__, __LINE__));
     if (words) {
-        e = hipMemcpy2DAsync(m->d_hm, m->hm_stride * 4ull, bits, row_stride_words * 8ull, words * 8ull, n_hap,
+        e = hipMemcpy2DAsync(d_hm, hm_stride * 4ull, bits, row_stride_words * 8ull, words * 8ull, n_hap,
                              hipMemcpyHostToDevice, ctx->stream);
         if (e != hipSuccess) return fail(hip_fail(e, "hipMemcpy2DAsync(upload)", __FILE__, __LINE__));
-        hipLaunchKernelGGL(hm_clear_tail_kernel, dim3((m->n_hap_pad + 255) / 256), dim3(256), 0, ctx->stream, m->d_hm,
-                           m->hm_stride, m->n_hap_pad, n_site, words * 2);
+        hipLaunchKernelGGL(hm_clear_tail_kernel, dim3((m->n_hap_pad + 255) / 256), dim3(256), 0, ctx->stream, d_hm, hm_stride,
+                           m->n_hap_pad, n_site, words * 2);
         if ((e = hipGetLastError()) != hipSuccess) return fail(hip_fail(e, "hm_clear_tail_kernel", __FILE__, __LINE__));
     }
-    rc = launch_hm_to_sb(ctx, m->d_hm, m->hm_stride, m->g, m->d_sb);
+    rc = launch_hm_to_sb(ctx, d_hm, hm_stride, m->g, m->d_sb);
     if (rc) return fail(rc);
+    if (want_rb) {
+        rc = launch_sb_to_hm(ctx, m->d_sb, m->g, 0, m->g.n_block, m->d_rb, 0, m->n_hap_pad, m->rb_nq);
+        if (rc) return fail(rc);
+    }
     e = hipStreamSynchronize(ctx->stream);  // the caller may free `bits` on return
     if (e != hipSuccess) return fail(hip_fail(e, "hipStreamSynchronize", __FILE__, __LINE__));
-    if (!(keep_flags & IMPOP_KEEP_HAP_MAJOR)) {
-        hipFree(m->d_hm);
-        m->d_hm = nullptr;
-        m->hm_bytes = 0;
-    }
+    hipFree(d_hm);
     *out = m;
     return IMPOP_OK;
 }
@@ -277,9 +295,7 @@ IMPOP_API int impop_matrix_synthetic(impop_ctx *ctx, uint32_t n_hap, uint64_t n_
                            wps, m->g.G, m->g.r, m->g.n_block, n_site, m->d_sb);
         if ((e = hipGetLastError()) != hipSuccess) return fail(hip_fail(e, "synth_sb_kernel", __FILE__, __LINE__));
         if (want_hm) {
-            e = hipMemsetAsync(m->d_hm, 0, m->hm_bytes, ctx->stream);
-            if (e != hipSuccess) return fail(hip_fail(e, "hipMemsetAsync", __FILE__, __LINE__));
-            rc = launch_sb_to_hm(ctx, m->d_sb, m->g, 0, m->g.n_block, m->d_hm, m->hm_stride, m->n_hap_pad);
+            rc = launch_sb_to_hm(ctx, m->d_sb, m->g, 0, m->g.n_block, m->d_rb, 0, m->n_hap_pad, m->rb_nq);
             if (rc) return fail(rc);
         }
     }
@@ -331,7 +347,7 @@ IMPOP_API int impop_matrix_info(const impop_matrix *m, uint32_t *n_hap, uint64_t
     REQUIRE(m, "impop_matrix_info: matrix is NULL");
     if (n_hap) *n_hap = m->g.n_hap;
     if (n_site) *n_site = m->g.n_site;
-    if (device_bytes) *device_bytes = m->sb_bytes + m->hm_bytes;
+    if (device_bytes) *device_bytes = m->sb_bytes + m->rb_bytes;
     if (bytes_per_site) *bytes_per_site = m->g.wps * 4;
     return IMPOP_OK;
 }
@@ -343,7 +359,7 @@ IMPOP_API int impop_matrix_free(impop_ctx *ctx, impop_matrix *m) {
         hipStreamSynchronize(ctx->stream);
     }
     if (m->d_sb) hipFree(m->d_sb);
-    if (m->d_hm) hipFree(m->d_hm);
+    if (m->d_rb) hipFree(m->d_rb);
     delete m;
     return IMPOP_OK;
 }

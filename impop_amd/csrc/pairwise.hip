@@ -10,258 +10,182 @@
 
 namespace impop {
 
-// ---- Gram kernel v2 ---------------------------------------------------------------------
-// 128 x 128 haplotype tile per 256-thread workgroup (upper-triangular tile grid x windows);
-// thread (ty, tx) owns the 8 x 8 outputs rows {ty+16r} x cols {tx+16c}.  The site axis is
-// consumed in 16-dword (512-site) chunks staged through LDS with row pitch 20 dwords: the
-// 16 distinct rows a wave touches per ds_read_b128 then start on distinct 4-bank groups
-// (tx*20 mod 64 = 0,20,40,60,16,...: all different multiples of 4) => conflict-free.  Per
-// chunk a thread issues 4x16 ds_read_b128 for 8*8*16 AND+BCNT pairs (1:32 LDS:VALU), so the
-// kernel is bound by the VALU popcount rate.  Global->LDS staging is double-buffered through
-// registers (loads for chunk t+1 are issued before the math of chunk t).  Diagonal tiles skip
-// the r > c sub-blocks (strictly below the diagonal for every thread), 28 of 64.
-constexpr int GT = 128;      // tile edge (haplotypes)
-constexpr int KC = 16;       // dwords per K-chunk
-constexpr int PITCH = 20;    // LDS row pitch (dwords)
+// ---- Gram kernel: int8 MFMA, register-only (no LDS, no barriers) ---------------------------
+// G[i][j] = sum_s x_i[s] x_j[s] as a dense contraction on the matrix cores: each lane expands the
+// bits of ITS rows to 0/1 bytes in registers and feeds v_mfma_i32_32x32x32_i8 (exact: int32
+// accumulation).  Design history, all measured on MI355X:
+//   * VALU AND + v_bcnt (128x128 tile, 8x8 register tile): v_bcnt_u32_b32 is a HALF-rate
+//     instruction on gfx950 (tools/micro/valu_rate.hip: 4.8 vs 2.55 cycles per wave-instruction),
+//     ceiling ~1e5 windows/s at n = 465, W = 50 000; reached 23 us/window.
+//   * int8 MFMA with bits expanded into LDS byte tiles: ds_write_b128 + one barrier per 64 sites
+//     dominate (LDS write path ~79 B/clk/CU); 9 us/window.
+//   * int8 MFMA, register-only, rows 1.6 MB apart (plain hap-major): every wave-load touched 32
+//     cache lines for 512 useful bytes and the address path, not the ALUs, set the pace; 9-11 us.
+//   * this kernel: the operand is stored ROW-GROUP-BLOCKED (RB32, internal.h) so one wave-load of
+//     a 128-site quad for 32 rows is 512 contiguous bytes.
+// One WAVE owns one 64 x 128 half of a 128 x 128 tile: 2 x 4 MFMA tiles of 32 x 32 = 128
+// accumulator registers, leaving room for TWO waves per SIMD (a lone wave issues one VALU
+// instruction per ~8 cycles, two or more reach one per 2.6 / 4.8 cycles).  Lane l supplies row
+// (l & 31) of each 32-row group and the 16 sites [16 (l>>5), +16) of a 32-site k-step.  Expansion:
+// y = x & 0x0F0F and z = (x >> 4) & 0x0F0F hold the four nibbles as clean bytes, v_mul_u32_u24
+// with an SDWA byte select spreads one nibble per instruction (nibble * 0x204081: copies at bits
+// 0-3, 7-10, 14-17, 21-24, no carries) and one AND keeps bits 0, 8, 16, 24: 12 VALU ops per
+// fragment, 6 fragments per 8 MFMAs.  MFMA and VALU runs of one wave do not overlap unless finely
+// interleaved (tools/micro/mfma_rate.hip: 257 + 368 -> 589 cycles), hence the software pipeline
+// (expand step t+1 under the MFMAs of step t) and the sched_group_barrier issue pattern.
+// Both MFMA operands use the same (lane>>5, byte) -> site mapping, so the result does not depend
+// on the instruction's internal k order; C/D map: col = lane&31, row = (reg&3)+8(reg>>2)+4(lane>>5).
+constexpr int GT = 128;  // tile edge (haplotypes)
 
 struct GramWindow {
     uint64_t site_begin, site_end;
 };
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-
-template <bool DIAG>
-__device__ __forceinline__ void gram_chunk_math(const uint32_t *__restrict__ As, const uint32_t *__restrict__ Bs,
-                                                uint32_t ty, uint32_t tx, int32_t (&acc)[8][8]) {
-#pragma unroll 1
-    for (int k4 = 0; k4 < KC / 4; ++k4) {
-        u32x4 a[8], b[8];
-#pragma unroll
-        for (int r = 0; r < 8; ++r) a[r] = *reinterpret_cast<const u32x4 *>(As + (ty + 16 * r) * PITCH + 4 * k4);
-#pragma unroll
-        for (int c = 0; c < 8; ++c) b[c] = *reinterpret_cast<const u32x4 *>(Bs + (tx + 16 * c) * PITCH + 4 * k4);
-#pragma unroll
-        for (int r = 0; r < 8; ++r)
-#pragma unroll
-            for (int c = 0; c < 8; ++c) {
-                if (DIAG && r > c) continue;
-                acc[r][c] += __popc(a[r].x & b[c].x) + __popc(a[r].y & b[c].y) + __popc(a[r].z & b[c].z) +
-                             __popc(a[r].w & b[c].w);
-            }
-    }
-}
-
-__global__ __launch_bounds__(256, 2) void gram_kernel(const uint32_t *__restrict__ hm, uint64_t hm_stride, uint32_t n_tiles,
-                                                   const GramWindow *__restrict__ wins, int32_t *__restrict__ out,
-                                                   uint32_t ld, uint64_t out_stride) {
-    __shared__ __attribute__((aligned(16))) uint32_t lds[2][2][GT * PITCH];  // [buffer][A|B]
-    // decode upper-triangular tile pair (ti <= tj) from blockIdx.x
-    uint32_t rem = blockIdx.x, ti = 0;
-    while (rem >= n_tiles - ti) { rem -= n_tiles - ti; ++ti; }
-    const uint32_t tj = ti + rem;
-    const bool diag = ti == tj;
-    const GramWindow w = wins[blockIdx.y];
-    const uint32_t tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
-    int32_t acc[8][8];
-#pragma unroll
-    for (int r = 0; r < 8; ++r)
-#pragma unroll
-        for (int c = 0; c < 8; ++c) acc[r][c] = 0;
-    if (w.site_end > w.site_begin) {
-        const uint64_t d0 = w.site_begin >> 5, d1 = (w.site_end + 31) >> 5;  // dword range of the window
-        const uint64_t c0 = d0 & ~3ull;                                        // 16-byte aligned start
-        const uint32_t first_mask = 0xFFFFFFFFu << (w.site_begin & 31);
-        const uint32_t last_mask = (w.site_end & 31) ? (0xFFFFFFFFu >> (32 - (w.site_end & 31))) : 0xFFFFFFFFu;
-        // staging map: 128 rows x 4 uint4 per tile = 512 uint4; thread t moves uint4 #t and #t+256
-        const uint32_t srow = tid >> 2, scol = (tid & 3) * 4;  // rows srow and srow+64
-        const uint32_t *gA = hm + (uint64_t)(ti * GT + srow) * hm_stride + scol;
-        const uint32_t *gB = hm + (uint64_t)(tj * GT + srow) * hm_stride + scol;
-        const uint64_t row64 = 64 * hm_stride;
-        auto mask_of = [&](uint64_t d) -> uint32_t {
-            uint32_t m = (d >= d0 && d < d1) ? 0xFFFFFFFFu : 0u;
-            if (d == d0) m &= first_mask;
-            if (d == d1 - 1) m &= last_mask;
-            return m;
-        };
-        u32x4 ra0, ra1, rb0, rb1;
-        auto fetch = [&](uint64_t dk) {
-            // rows are padded to a multiple of 4 dwords and cover every block of the matrix, so a
-            // 16-byte load at an aligned dword < hm_stride is always in bounds
-            const bool in = dk + scol < hm_stride;
-            const u32x4 z = {0u, 0u, 0u, 0u};
-            ra0 = in ? *reinterpret_cast<const u32x4 *>(gA + dk) : z;
-            ra1 = in ? *reinterpret_cast<const u32x4 *>(gA + row64 + dk) : z;
-            rb0 = in ? *reinterpret_cast<const u32x4 *>(gB + dk) : z;
-            rb1 = in ? *reinterpret_cast<const u32x4 *>(gB + row64 + dk) : z;
-            const uint64_t d = dk + scol;
-            const u32x4 m = {mask_of(d), mask_of(d + 1), mask_of(d + 2), mask_of(d + 3)};
-            ra0 &= m; ra1 &= m;  // masking one operand suffices for AND
-        };
-        auto stash = [&](int buf) {
-            *reinterpret_cast<u32x4 *>(&lds[buf][0][srow * PITCH + scol]) = ra0;
-            *reinterpret_cast<u32x4 *>(&lds[buf][0][(srow + 64) * PITCH + scol]) = ra1;
-            *reinterpret_cast<u32x4 *>(&lds[buf][1][srow * PITCH + scol]) = rb0;
-            *reinterpret_cast<u32x4 *>(&lds[buf][1][(srow + 64) * PITCH + scol]) = rb1;
-        };
-        fetch(c0);
-        stash(0);
-        __syncthreads();
-        int buf = 0;
-        for (uint64_t dk = c0; dk < d1; dk += KC) {
-            const bool more = dk + KC < d1;
-            if (more) fetch(dk + KC);
-            if (diag) gram_chunk_math<true>(lds[buf][0], lds[buf][1], ty, tx, acc);
-            else gram_chunk_math<false>(lds[buf][0], lds[buf][1], ty, tx, acc);
-            if (more) stash(buf ^ 1);
-            __syncthreads();
-            buf ^= 1;
-        }
-    }
-    int32_t *o = out + (uint64_t)blockIdx.y * out_stride;
-#pragma unroll
-    for (int r = 0; r < 8; ++r)
-#pragma unroll
-        for (int c = 0; c < 8; ++c) {
-            if (diag && r > c) continue;  // lower half of a diagonal tile: filled by symmetry on export
-            o[(uint64_t)(ti * GT + ty + 16 * r) * ld + (tj * GT + tx + 16 * c)] = acc[r][c];
-        }
-}
-
-// ---- Gram kernel v3: int8 MFMA ----------------------------------------------------------------
-// G[i][j] = sum_s x_i[s] x_j[s] as a dense contraction on the matrix cores: bits are expanded to
-// 0/1 bytes in LDS and multiplied with v_mfma_i32_32x32x32_i8 (exact: int32 accumulation).
-// Measured motivation (tools/micro/valu_rate.hip): v_bcnt_u32_b32 is a half-rate instruction on
-// gfx950 (4.8 vs 2.55 cycles per wave-instruction for v_and), so the VALU popcount form tops out
-// near 1e5 windows/s at n = 465, W = 50 000, while int8 MFMA has ~10x the raw MAC rate.
-//
-// Workgroup = 128 x 128 haplotype tile, 4 waves as 2 x 2, each wave 2 x 2 MFMA tiles of 32 x 32.
-// The site axis is consumed in 512-site super-chunks (16 dwords per row, prefetched one ahead in
-// registers); thread (r = tid/2, h = tid%2) owns dwords 8h..8h+7 of row r of BOTH operand tiles.
-// A sub-chunk (K = 64) takes dword j of h = 0 and dword j of h = 1: the sites inside a sub-chunk
-// are not contiguous, which is irrelevant for a sum over sites, and it keeps every lane busy in
-// the expansion.  Byte rows in LDS have pitch 80 B so that ds_read_b128 fragment reads of 16
-// consecutive rows start in distinct 16-byte bank groups.  Both MFMA operands use the same
-// (lane>>5, byte) -> site mapping, so the result does not depend on the instruction's internal
-// k order; the C/D map is the documented col = lane&31, row = (reg&3) + 8(reg>>2) + 4(lane>>5).
-constexpr int BP = 80;  // LDS byte-row pitch
-
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x16 __attribute__((ext_vector_type(16)));
 
-// 4 bits -> 4 bytes of 0/1: (nibble * 0x204081) & 0x01010101 (bit i lands on bit 8i)
-__device__ __forceinline__ uint32_t expand_nibble(uint32_t x, int i) {
-    return __umul24((x >> (4 * i)) & 0xFFu, 0x204081u) & 0x01010101u;  // bits 4..7 of the byte land off the kept positions
+__device__ __forceinline__ uint32_t spread_byte0(uint32_t v, uint32_t k) {
+    uint32_t r;
+    asm("v_mul_u32_u24_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:DWORD"
+        : "=v"(r) : "v"(v), "v"(k));
+    return r;
 }
-__device__ __forceinline__ void expand_dword_to_lds(uint32_t x, unsigned char *dst /*32 bytes, 16-B aligned*/) {
-    u32x4 lo = {expand_nibble(x, 0), expand_nibble(x, 1), expand_nibble(x, 2), expand_nibble(x, 3)};
-    u32x4 hi = {expand_nibble(x, 4), expand_nibble(x, 5), expand_nibble(x, 6), expand_nibble(x, 7)};
-    *reinterpret_cast<u32x4 *>(dst) = lo;
-    *reinterpret_cast<u32x4 *>(dst + 16) = hi;
+__device__ __forceinline__ uint32_t spread_byte1(uint32_t v, uint32_t k) {
+    uint32_t r;
+    asm("v_mul_u32_u24_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD"
+        : "=v"(r) : "v"(v), "v"(k));
+    return r;
+}
+__device__ __forceinline__ i32x4 expand16(uint32_t xs /* the lane's 16 bits in the low half */, uint32_t kmul) {
+    const uint32_t y = xs & 0x0F0Fu;         // nibbles 0, 2 as bytes 0, 1
+    const uint32_t z = (xs >> 4) & 0x0F0Fu;  // nibbles 1, 3 as bytes 0, 1
+    i32x4 r;
+    r.x = (int)(spread_byte0(y, kmul) & 0x01010101u);
+    r.y = (int)(spread_byte0(z, kmul) & 0x01010101u);
+    r.z = (int)(spread_byte1(y, kmul) & 0x01010101u);
+    r.w = (int)(spread_byte1(z, kmul) & 0x01010101u);
+    return r;
 }
 
-__global__ __launch_bounds__(256, 2) void gram_mfma_kernel(const uint32_t *__restrict__ hm, uint64_t hm_stride,
-                                                           uint32_t n_tiles, const GramWindow *__restrict__ wins,
-                                                           int32_t *__restrict__ out, uint32_t ld, uint64_t out_stride) {
-    __shared__ __attribute__((aligned(16))) unsigned char lds[2][2][GT * BP];  // [buffer][A|B] byte tiles, 40 KB
-    uint32_t rem = blockIdx.x, ti = 0;
+// grid: 1-D, tasks = (window, tile pair, row half).  Consecutive block ids are dealt round-robin
+// over the 8 XCDs, so id % 8 selects the window inside a group of 8 windows: all tasks of one
+// window then share one XCD's L2 (speed only; any placement is correct).
+__global__ __launch_bounds__(64, 2) void gram_mfma_kernel(const uint32_t *__restrict__ rb, uint64_t nq_row,
+                                                          uint32_t n_tiles, uint32_t tasks_per_win, uint32_t n_win,
+                                                          const GramWindow *__restrict__ wins, int32_t *__restrict__ out,
+                                                          uint32_t ld, uint64_t out_stride) {
+    const uint32_t id = blockIdx.x;
+    uint32_t win, task;
+    if (n_win >= 8) {
+        const uint32_t grp = id / (8 * tasks_per_win), within = id % (8 * tasks_per_win);
+        win = grp * 8 + (within & 7);
+        task = within >> 3;
+        if (win >= n_win) return;
+    } else {  // few windows: spread each window's tasks over all XCDs instead
+        win = id / tasks_per_win;
+        task = id % tasks_per_win;
+    }
+    uint32_t rem = task >> 1, ti = 0;
+    const uint32_t half = task & 1;
     while (rem >= n_tiles - ti) { rem -= n_tiles - ti; ++ti; }
     const uint32_t tj = ti + rem;
-    const bool diag = ti == tj;
-    const GramWindow w = wins[blockIdx.y];
-    const uint32_t tid = threadIdx.x, lane = tid & 63;
-    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6), wr = wave >> 1, wc = wave & 1;
-    const bool wave_active = !(diag && wr == 1 && wc == 0);  // strictly below the diagonal: nothing to compute
-    i32x16 acc[2][2];
+    const GramWindow w = wins[win];
+    const uint32_t lane = threadIdx.x & 63, r32 = lane & 31, sh = 16 * (lane >> 5);
+    const uint32_t row0 = ti * GT + 64 * half;
+    const uint32_t kmul = 0x204081u;
+    i32x16 acc[2][4];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
+        for (int b = 0; b < 4; ++b)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[a][b][e] = 0;
     if (w.site_end > w.site_begin) {
         const uint64_t d0 = w.site_begin >> 5, d1 = (w.site_end + 31) >> 5;
         const uint64_t c0 = d0 & ~3ull;
+        // everything inside the loop is 32-bit and relative to c0 (gfx9 has no 64-bit scalar
+        // less-than: 64-bit loop/mask compares would run on the VALU and split the body into blocks)
+        const uint32_t f = (uint32_t)(d0 - c0);        // first window dword, 0..3
+        const uint32_t l = (uint32_t)(d1 - 1 - c0);    // last window dword
+        const uint32_t nq = (l >> 2) + 1;              // quads to process
         const uint32_t first_mask = 0xFFFFFFFFu << (w.site_begin & 31);
         const uint32_t last_mask = (w.site_end & 31) ? (0xFFFFFFFFu >> (32 - (w.site_end & 31))) : 0xFFFFFFFFu;
-        const uint32_t r = tid >> 1, h = tid & 1;
-        const uint32_t *gA = hm + (uint64_t)(ti * GT + r) * hm_stride + 8 * h;
-        const uint32_t *gB = hm + (uint64_t)(tj * GT + r) * hm_stride + 8 * h;
-        auto mask_of = [&](uint64_t d) -> uint32_t {
-            uint32_t m = (d >= d0 && d < d1) ? 0xFFFFFFFFu : 0u;
-            if (d == d0) m &= first_mask;
-            if (d == d1 - 1) m &= last_mask;
+        // RB32: dword (row, d) @ (((row>>5) * nq_row + (d>>2)) * 32 + (row&31)) * 4 + (d&3)
+        const uint32_t *gA = rb + (((uint64_t)(row0 >> 5) * nq_row + (c0 >> 2)) * 32 + r32) * 4;
+        const uint32_t *gB = rb + (((uint64_t)((tj * GT) >> 5) * nq_row + (c0 >> 2)) * 32 + r32) * 4;
+        const uint64_t g32 = nq_row * 128;  // dwords between consecutive 32-row groups
+        auto mask_of = [&](uint32_t d) -> uint32_t {  // wave-uniform, d relative to c0
+            uint32_t m = (d >= f && d <= l) ? 0xFFFFFFFFu : 0u;
+            if (d == f) m &= first_mask;
+            if (d == l) m &= last_mask;
             return m;
         };
-        u32x4 ca0, ca1, cb0, cb1, na0, na1, nb0, nb1;  // current / next super-chunk: 8 dwords of A and of B
-        auto fetch = [&](uint64_t dk) {
-            const u32x4 z = {0u, 0u, 0u, 0u};
-            const uint64_t d = dk + 8 * h;
-            const bool in0 = d < hm_stride, in1 = d + 4 < hm_stride;
-            na0 = in0 ? *reinterpret_cast<const u32x4 *>(gA + dk) : z;
-            na1 = in1 ? *reinterpret_cast<const u32x4 *>(gA + dk + 4) : z;
-            nb0 = in0 ? *reinterpret_cast<const u32x4 *>(gB + dk) : z;
-            nb1 = in1 ? *reinterpret_cast<const u32x4 *>(gB + dk + 4) : z;
-            const u32x4 m0 = {mask_of(d), mask_of(d + 1), mask_of(d + 2), mask_of(d + 3)};
-            const u32x4 m1 = {mask_of(d + 4), mask_of(d + 5), mask_of(d + 6), mask_of(d + 7)};
-            na0 &= m0; na1 &= m1;  // a masked A byte is 0 => the product is 0
+        u32x4 qa[2], qb[4], na[2], nb[4];
+        // the allocation carries one quad of slack per row group, so the one-quad-ahead prefetch
+        // is always in bounds (whatever it reads past the window is masked to zero on the A side)
+        auto fetch = [&](uint32_t qi) {
+#pragma unroll
+            for (int g = 0; g < 2; ++g) na[g] = *reinterpret_cast<const u32x4 *>(gA + g * g32 + (uint64_t)qi * 128);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) nb[g] = *reinterpret_cast<const u32x4 *>(gB + g * g32 + (uint64_t)qi * 128);
         };
-        unsigned char *const wrA = &lds[0][0][r * BP + 32 * h], *const wrB = &lds[0][1][r * BP + 32 * h];
-        constexpr int BUF = 2 * GT * BP;  // bytes between the two buffers
-        const uint32_t frag_off = (lane & 31) * BP + 16 * (lane >> 5);
-        fetch(c0);
-        for (uint64_t dk = c0; dk < d1; dk += 16) {
-            ca0 = na0; ca1 = na1; cb0 = nb0; cb1 = nb1;
-            if (dk + 16 < d1) fetch(dk + 16);
-            // sub-chunk 0 of this super-chunk
-            expand_dword_to_lds(ca0.x, wrA);
-            expand_dword_to_lds(cb0.x, wrB);
-            __syncthreads();
+        auto adopt = [&](uint32_t q4) {  // next quad -> current quad, window mask applied to A
+            const u32x4 m = {mask_of(q4), mask_of(q4 + 1), mask_of(q4 + 2), mask_of(q4 + 3)};
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int buf = j & 1;
-                if (j < 7) {  // expand sub-chunk j+1 into the other buffer while this one feeds the MFMAs
-                    const uint32_t xa = (j + 1) < 4 ? ca0[(j + 1) & 3] : ca1[(j + 1) & 3];
-                    const uint32_t xb = (j + 1) < 4 ? cb0[(j + 1) & 3] : cb1[(j + 1) & 3];
-                    expand_dword_to_lds(xa, wrA + (buf ^ 1) * BUF);
-                    expand_dword_to_lds(xb, wrB + (buf ^ 1) * BUF);
-                }
-                if (wave_active) {
-                    const unsigned char *pa = &lds[buf][0][(64 * wr) * BP + frag_off];
-                    const unsigned char *pb = &lds[buf][1][(64 * wc) * BP + frag_off];
+            for (int g = 0; g < 2; ++g) qa[g] = na[g] & m;  // a zero A byte kills the product
 #pragma unroll
-                    for (int ks = 0; ks < 2; ++ks) {
-                        const i32x4 a0 = *reinterpret_cast<const i32x4 *>(pa + 32 * ks);
-                        const i32x4 a1 = *reinterpret_cast<const i32x4 *>(pa + 32 * BP + 32 * ks);
-                        const i32x4 b0 = *reinterpret_cast<const i32x4 *>(pb + 32 * ks);
-                        const i32x4 b1 = *reinterpret_cast<const i32x4 *>(pb + 32 * BP + 32 * ks);
-                        acc[0][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, b0, acc[0][0], 0, 0, 0);
-                        acc[0][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a0, b1, acc[0][1], 0, 0, 0);
-                        acc[1][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, b0, acc[1][0], 0, 0, 0);
-                        acc[1][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a1, b1, acc[1][1], 0, 0, 0);
-                    }
+            for (int g = 0; g < 4; ++g) qb[g] = nb[g];
+        };
+        i32x4 fa[2], fb[4], ga[2], gb[4];
+        fetch(0);
+        adopt(0);
+        fetch(1);
+#pragma unroll
+        for (int g = 0; g < 2; ++g) fa[g] = expand16(qa[g][0] >> sh, kmul);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) fb[g] = expand16(qb[g][0] >> sh, kmul);
+        for (uint32_t qi = 0; qi < nq; ++qi) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (q == 3) {  // the step after this one starts the next quad (all-zero masks past the window)
+                    adopt(4 * qi + 4);
+                    if (qi + 2 < nq) fetch(qi + 2);
                 }
-                __syncthreads();
+                const int qn = (q + 1) & 3;
+#pragma unroll
+                for (int g = 0; g < 2; ++g) ga[g] = expand16(qa[g][qn] >> sh, kmul);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) gb[g] = expand16(qb[g][qn] >> sh, kmul);
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int b = 0; b < 4; ++b)
+                        acc[a][b] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[a], fb[b], acc[a][b], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x002, 10, 0);  // 10 VALU
+                }
+#pragma unroll
+                for (int g = 0; g < 2; ++g) fa[g] = ga[g];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) fb[g] = gb[g];
             }
         }
     }
-    if (wave_active) {
-        int32_t *o = out + (uint64_t)blockIdx.y * out_stride;
+    int32_t *o = out + (uint64_t)win * out_stride;
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
+    for (int a = 0; a < 2; ++a)
 #pragma unroll
-            for (int nt = 0; nt < 2; ++nt)
+        for (int b = 0; b < 4; ++b)
 #pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const uint32_t row = ti * GT + 64 * wr + 32 * mt + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
-                    const uint32_t col = tj * GT + 64 * wc + 32 * nt + (lane & 31);
-                    o[(uint64_t)row * ld + col] = acc[mt][nt][e];
-                }
-    }
+            for (int e = 0; e < 16; ++e) {
+                const uint32_t row = row0 + 32 * a + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+                const uint32_t col = tj * GT + 32 * b + r32;
+                o[(uint64_t)row * ld + col] = acc[a][b][e];
+            }
 }
-
-#ifndef IMPOP_GRAM_MFMA
-#define IMPOP_GRAM_MFMA 1  // 0: VALU AND+BCNT kernel (kept for A/B measurements)
-#endif
 
 // mirror the upper tiles into the lower triangle (only for host export)
 __global__ void gram_symmetrize_kernel(int32_t *g, uint32_t ld) {
@@ -305,15 +229,11 @@ __global__ void pairwise_finalize_kernel(PairFinalIn in, uint64_t n_windows, uin
 
 static int launch_gram(impop_ctx *ctx, const impop_matrix *m, const GramWindow *d_wins, uint32_t n_win, int32_t *d_out) {
     const uint32_t T = m->n_hap_pad / GT;
-    const uint32_t pairs = T * (T + 1) / 2;
-    REQUIRE(n_win <= 65535, "gram: at most 65535 windows per launch");
-#if IMPOP_GRAM_MFMA
-    hipLaunchKernelGGL(gram_mfma_kernel, dim3(pairs, n_win), dim3(256), 0, ctx->stream, m->d_hm, m->hm_stride, T, d_wins,
-                       d_out, m->n_hap_pad, (uint64_t)m->n_hap_pad * m->n_hap_pad);
-#else
-    hipLaunchKernelGGL(gram_kernel, dim3(pairs, n_win), dim3(256), 0, ctx->stream, m->d_hm, m->hm_stride, T, d_wins, d_out,
-                       m->n_hap_pad, (uint64_t)m->n_hap_pad * m->n_hap_pad);
-#endif
+    const uint32_t tasks_per_win = T * (T + 1);  // upper-triangular tile pairs x 2 row halves
+    const uint64_t grid = (uint64_t)(n_win >= 8 ? (n_win + 7) / 8 * 8 : n_win) * tasks_per_win;
+    REQUIRE(grid < 0x7FFFFFFFull, "gram: too many tasks for one launch");
+    hipLaunchKernelGGL(gram_mfma_kernel, dim3((uint32_t)grid), dim3(64), 0, ctx->stream, m->d_rb, m->rb_nq, T, tasks_per_win,
+                       n_win, d_wins, d_out, m->n_hap_pad, (uint64_t)m->n_hap_pad * m->n_hap_pad);
     HIP_TRY(hipGetLastError());
     return IMPOP_OK;
 }
@@ -337,7 +257,7 @@ using namespace impop;
 
 static int check_pairwise_args(impop_ctx *ctx, const impop_matrix *m, uint64_t s0, uint64_t s1, const char *fn) {
     REQUIRE(ctx && m, "%s: NULL argument", fn);
-    REQUIRE(m->d_hm, "%s: matrix was created without IMPOP_KEEP_HAP_MAJOR", fn);
+    REQUIRE(m->d_rb, "%s: matrix was created without IMPOP_KEEP_HAP_MAJOR", fn);
     REQUIRE(s0 <= s1 && s1 <= m->g.n_site, "%s: bad site range [%llu,%llu)", fn, (unsigned long long)s0,
             (unsigned long long)s1);
     REQUIRE(s1 - s0 < (1ull << 31), "%s: window longer than 2^31 sites overflows int32 counts", fn);
@@ -406,7 +326,7 @@ IMPOP_API int impop_pairwise_scan(impop_ctx *ctx, const impop_matrix *m, const i
                                   const impop_pairwise_params *params, impop_pairwise_stats *out_host) {
     REQUIRE(ctx && m && params, "impop_pairwise_scan: NULL argument");
     REQUIRE(params->struct_size == sizeof(impop_pairwise_params), "impop_pairwise_params.struct_size mismatch");
-    REQUIRE(m->d_hm, "impop_pairwise_scan: matrix was created without IMPOP_KEEP_HAP_MAJOR");
+    REQUIRE(m->d_rb, "impop_pairwise_scan: matrix was created without IMPOP_KEEP_HAP_MAJOR");
     REQUIRE(params->identity_kind == IMPOP_IDENTITY_MATCH || params->identity_kind == IMPOP_IDENTITY_DICE,
             "impop_pairwise_scan: unknown identity kind");
     REQUIRE(params->round_digits <= 19, "impop_pairwise_scan: round_digits > 19 unsupported");

@@ -70,7 +70,7 @@ int impop_ctx_device_name(impop_ctx *ctx, char *buf, size_t buflen);
  * is 1 iff haplotype i carries the allele at site s.
  * keep flags: which device layouts to materialise. */
 #define IMPOP_KEEP_SITE_BLOCKED 1u /* SB64 layout used by impop_scan (always kept) */
-#define IMPOP_KEEP_HAP_MAJOR 2u    /* hap-major copy needed by impop_pairwise_* */
+#define IMPOP_KEEP_HAP_MAJOR 2u    /* haplotype-major (row-group-blocked) copy needed by impop_pairwise_* */
 
 int impop_matrix_upload(impop_ctx *ctx, const uint64_t *bits_hap_major, uint32_t n_hap, uint64_t n_site,
                         uint64_t row_stride_words, uint32_t keep_flags, impop_matrix **out);

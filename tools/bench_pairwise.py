@@ -18,7 +18,7 @@ VALU_PEAK_LANEOPS = 256 * 128 * 2.4e9  # 256 CUs x 128 lane-ops/clk x 2.4 GHz (M
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--windows", type=int, default=64)
+    ap.add_argument("--windows", type=int, default=256)
     ap.add_argument("--window", type=int, default=50000)
     ap.add_argument("--big-hap", type=int, default=4096)
     ap.add_argument("--big-sites", type=int, default=1_000_000)

@@ -71,11 +71,15 @@ __device__ __forceinline__ i32x4 expand16(uint32_t xs /* the lane's 16 bits in t
 // grid: 1-D, tasks = (window, tile pair, row half).  Consecutive block ids are dealt round-robin
 // over the 8 XCDs, so id % 8 selects the window inside a group of 8 windows: all tasks of one
 // window then share one XCD's L2 (speed only; any placement is correct).
+// ksplit > 1: the site range of a window is cut into ksplit slices handled by different waves that
+// atomicAdd into a zero-initialised output (integer adds commute: still bit-reproducible); used
+// when there are too few (window, tile) tasks to put two waves on every SIMD.
 __global__ __launch_bounds__(64, 2) void gram_mfma_kernel(const uint32_t *__restrict__ rb, uint64_t nq_row,
                                                           uint32_t n_tiles, uint32_t tasks_per_win, uint32_t n_win,
-                                                          const GramWindow *__restrict__ wins, int32_t *__restrict__ out,
-                                                          uint32_t ld, uint64_t out_stride) {
-    const uint32_t id = blockIdx.x;
+                                                          uint32_t ksplit, const GramWindow *__restrict__ wins,
+                                                          int32_t *__restrict__ out, uint32_t ld, uint64_t out_stride) {
+    const uint32_t ks = blockIdx.x % ksplit;
+    const uint32_t id = blockIdx.x / ksplit;
     uint32_t win, task;
     if (n_win >= 8) {
         const uint32_t grp = id / (8 * tasks_per_win), within = id % (8 * tasks_per_win);
@@ -108,7 +112,9 @@ __global__ __launch_bounds__(64, 2) void gram_mfma_kernel(const uint32_t *__rest
         // less-than: 64-bit loop/mask compares would run on the VALU and split the body into blocks)
         const uint32_t f = (uint32_t)(d0 - c0);        // first window dword, 0..3
         const uint32_t l = (uint32_t)(d1 - 1 - c0);    // last window dword
-        const uint32_t nq = (l >> 2) + 1;              // quads to process
+        const uint32_t nq_all = (l >> 2) + 1;          // quads of the window
+        const uint32_t qbeg = (uint32_t)((uint64_t)nq_all * ks / ksplit);
+        const uint32_t nq = (uint32_t)((uint64_t)nq_all * (ks + 1) / ksplit);  // this slice: quads [qbeg, nq)
         const uint32_t first_mask = 0xFFFFFFFFu << (w.site_begin & 31);
         const uint32_t last_mask = (w.site_end & 31) ? (0xFFFFFFFFu >> (32 - (w.site_end & 31))) : 0xFFFFFFFFu;
         // RB32: dword (row, d) @ (((row>>5) * nq_row + (d>>2)) * 32 + (row&31)) * 4 + (d&3)
@@ -138,14 +144,14 @@ __global__ __launch_bounds__(64, 2) void gram_mfma_kernel(const uint32_t *__rest
             for (int g = 0; g < 4; ++g) qb[g] = nb[g];
         };
         i32x4 fa[2], fb[4], ga[2], gb[4];
-        fetch(0);
-        adopt(0);
-        fetch(1);
+        fetch(qbeg);
+        adopt(4 * qbeg);
+        fetch(qbeg + 1);
 #pragma unroll
         for (int g = 0; g < 2; ++g) fa[g] = expand16(qa[g][0] >> sh, kmul);
 #pragma unroll
         for (int g = 0; g < 4; ++g) fb[g] = expand16(qb[g][0] >> sh, kmul);
-        for (uint32_t qi = 0; qi < nq; ++qi) {
+        for (uint32_t qi = qbeg; qi < nq; ++qi) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 if (q == 3) {  // the step after this one starts the next quad (all-zero masks past the window)
@@ -183,7 +189,8 @@ __global__ __launch_bounds__(64, 2) void gram_mfma_kernel(const uint32_t *__rest
             for (int e = 0; e < 16; ++e) {
                 const uint32_t row = row0 + 32 * a + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
                 const uint32_t col = tj * GT + 32 * b + r32;
-                o[(uint64_t)row * ld + col] = acc[a][b][e];
+                if (ksplit == 1) o[(uint64_t)row * ld + col] = acc[a][b][e];
+                else atomicAdd(&o[(uint64_t)row * ld + col], acc[a][b][e]);
             }
 }
 
@@ -230,10 +237,18 @@ __global__ void pairwise_finalize_kernel(PairFinalIn in, uint64_t n_windows, uin
 static int launch_gram(impop_ctx *ctx, const impop_matrix *m, const GramWindow *d_wins, uint32_t n_win, int32_t *d_out) {
     const uint32_t T = m->n_hap_pad / GT;
     const uint32_t tasks_per_win = T * (T + 1);  // upper-triangular tile pairs x 2 row halves
-    const uint64_t grid = (uint64_t)(n_win >= 8 ? (n_win + 7) / 8 * 8 : n_win) * tasks_per_win;
+    uint64_t grid = (uint64_t)(n_win >= 8 ? (n_win + 7) / 8 * 8 : n_win) * tasks_per_win;
+    // two waves per SIMD on every CU = 8 * n_cu resident waves; aim at >= 4 rounds of them so the
+    // last, partially filled round does not dominate, and split the site axis when there are fewer tasks
+    const uint64_t want = 32ull * (uint64_t)(ctx->n_cu > 0 ? ctx->n_cu : 256);
+    uint32_t ksplit = 1;
+    while (grid * ksplit < want && ksplit < 64) ksplit *= 2;
+    if (ksplit > 1)
+        HIP_TRY(hipMemsetAsync(d_out, 0, (size_t)n_win * m->n_hap_pad * m->n_hap_pad * sizeof(int32_t), ctx->stream));
+    grid *= ksplit;
     REQUIRE(grid < 0x7FFFFFFFull, "gram: too many tasks for one launch");
     hipLaunchKernelGGL(gram_mfma_kernel, dim3((uint32_t)grid), dim3(64), 0, ctx->stream, m->d_rb, m->rb_nq, T, tasks_per_win,
-                       n_win, d_wins, d_out, m->n_hap_pad, (uint64_t)m->n_hap_pad * m->n_hap_pad);
+                       n_win, ksplit, d_wins, d_out, m->n_hap_pad, (uint64_t)m->n_hap_pad * m->n_hap_pad);
     HIP_TRY(hipGetLastError());
     return IMPOP_OK;
 }

@@ -106,6 +106,12 @@ SIGNATURES = {
     "impop_tajimas_d": (C.c_int, [_vp, _i64p, _f64p, _f64p, C.c_uint64, _f64p, _f64p]),
     "impop_cluster_from_identity": (C.c_int, [_vp, _f64p, C.c_uint32, C.c_double, _u32p, _u32p, _u32p]),
     "impop_py_round": (C.c_int, [_vp, _f64p, C.c_uint64, C.c_int, _f64p]),
+    "impop_sim_parse": (C.c_int, [C.c_char_p, C.c_int, C.POINTER(_vp)]),
+    "impop_sim_info": (C.c_int, [_vp, _u32p, _u64p, _u64p, _i64p, _u64p]),
+    "impop_sim_names": (C.c_int, [_vp, C.c_char_p]),
+    "impop_sim_bad_text": (C.c_int, [_vp, C.c_char_p, C.c_size_t]),
+    "impop_sim_dense": (C.c_int, [_vp, _f64p]),
+    "impop_sim_free": (C.c_int, [_vp]),
 }
 
 _lib = None

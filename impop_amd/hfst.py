@@ -7,7 +7,7 @@ import numpy as np
 
 from .popnames import canonicalize_identifier, expand_population, read_subset_file  # noqa: F401
 from .runtime import default_context
-from .simfile import densify
+from .simfile import densify, read_dense  # noqa: F401
 from .simfile import read_similarity_file_hfst as read_similarity_file  # noqa: F401  (h-fst.py:84)
 
 
@@ -35,6 +35,13 @@ def calculate_diversity(similarities, seq_set1, seq_set2=None, round_digits=None
 
 def calculate_fst(similarities, pop_a, pop_b, sequence_length=None, round_digits=None, log_file=None, ctx=None):
     """h-fst.calculate_fst (h-fst.py:173-249) -> dict(fst, pi_a, pi_b, pi_xy, dxy, da)."""
+    names = sorted(set(pop_a) | set(pop_b) | {k for pair in similarities for k in pair})
+    dense = densify(similarities, names)
+    return calculate_fst_dense(names, dense, pop_a, pop_b, sequence_length, round_digits, log_file, ctx)
+
+
+def calculate_fst_dense(names, dense, pop_a, pop_b, sequence_length=None, round_digits=None, log_file=None, ctx=None):
+    """calculate_fst on an already densified table (what the drop-in CLI calls after the native ingest)."""
     def log_print(msg):
         if log_file:
             print(msg, file=log_file)
@@ -45,8 +52,16 @@ def calculate_fst(similarities, pop_a, pop_b, sequence_length=None, round_digits
         pop_a = pop_a - overlap
         pop_b = pop_b - overlap
     ctx = ctx or default_context()
-    names = sorted(set(pop_a) | set(pop_b) | {k for pair in similarities for k in pair})
-    dense = densify(similarities, names)
+    known = set(names)
+    extra = sorted((set(pop_a) | set(pop_b)) - known)
+    if extra:  # population members absent from the table: rows/cols of NaN (all their pairs are "missing")
+        n0 = len(names)
+        names = list(names) + extra
+        order = sorted(range(len(names)), key=lambda i: names[i])
+        big = np.full((len(names), len(names)), np.nan)
+        big[:n0, :n0] = dense
+        dense = big[np.ix_(order, order)]
+        names = [names[i] for i in order]
     L = sequence_length if (sequence_length and sequence_length > 0) else None
     out, cnt = ctx.fst_from_identity(dense, _flags(names, pop_a), _flags(names, pop_b), L, round_digits)
     log_print("FST Calculation")

@@ -6,6 +6,7 @@ import math
 
 from .runtime import default_context
 from .simfile import densify
+from .simfile import read_dense  # noqa: F401
 from .simfile import read_similarity_file_pica2 as read_similarity_file  # noqa: F401  (pica2.py:6)
 
 
@@ -26,13 +27,24 @@ def analyze_similarity_matrix(similarity_dict, elements, pair_count, threshold=1
         for key in list(similarity_dict.keys()):
             similarity_dict[key] = round(similarity_dict[key], round_digits)
     names = sorted(elements)
+    dense = densify(similarity_dict, names)
+    # values are already rounded in the dict; the device rounds again, which is idempotent
+    return analyze_dense(names, dense, pair_count, threshold, sequence_length, log_file, round_digits, ctx)
+
+
+def analyze_dense(names, dense, pair_count, threshold=1.0, sequence_length=None, log_file=None, round_digits=None,
+                  ctx=None):
+    """Same analysis on an already densified table (sorted names, [n,n] identity, NaN = absent):
+    what the drop-in CLI calls after the native .sim ingest (simfile.read_dense)."""
+    def log_print(message):
+        if log_file:
+            print(message, file=log_file)
+
     log_print(f"Loaded {pair_count} pairwise similarities")
-    log_print(f"Found {len(elements)} unique elements")
+    log_print(f"Found {len(names)} unique elements")
     if round_digits is not None:
         log_print(f"Rounded similarities to {round_digits} decimal places")
     ctx = ctx or default_context()
-    dense = densify(similarity_dict, names)
-    # values are already rounded in the dict; the device rounds again, which is idempotent
     pi, pi_site, group_of, n_groups = ctx.pi_from_identity(dense, threshold, round_digits, sequence_length)
     groups = [[] for _ in range(n_groups)]
     for name, g in zip(names, group_of):

@@ -3,6 +3,7 @@ densification the GPU kernels consume.  Pure marshalling: no statistics here."""
 from __future__ import annotations
 
 import csv
+import os
 import sys
 from typing import Dict, Iterable, List, Sequence, Set, Tuple
 
@@ -97,3 +98,39 @@ def densify(similarity_dict, names: Sequence[str]) -> np.ndarray:
         out[i, j] = v
         out[j, i] = v
     return out
+
+
+def read_dense(filename, flavor: str = "pica2"):
+    """Fast ingest used by the drop-in CLIs: (sorted names, dense [n,n] identity with NaN for absent
+    pairs, number of data rows).  Clean tab-separated files go through the native parser in
+    libimpop_hip.so (impop_sim_parse); any file shape it declines (quotes, short rows, unusual
+    number syntax, missing columns) — and every error path — goes through the reference-faithful
+    Python readers above, so messages and exit codes are the reference's."""
+    import ctypes as C
+
+    from . import _lib
+    lib = _lib.load()
+    h = C.c_void_p()
+    rc = lib.impop_sim_parse(os.fsencode(filename), 0 if flavor == "pica2" else 1, C.byref(h))
+    if rc == 0:
+        try:
+            n, rows, nb, bad_line, n_bad = C.c_uint32(), C.c_uint64(), C.c_uint64(), C.c_int64(), C.c_uint64()
+            _lib.check(lib.impop_sim_info(h, C.byref(n), C.byref(rows), C.byref(nb), C.byref(bad_line), C.byref(n_bad)))
+            if bad_line.value < 0 and n_bad.value == 0:
+                buf = C.create_string_buffer(max(nb.value, 1))
+                _lib.check(lib.impop_sim_names(h, buf))
+                names = [x.decode("utf-8", "surrogateescape") for x in buf.raw[: nb.value].split(b"\0")[: n.value]]
+                dense = np.empty((n.value, n.value))
+                _lib.check(lib.impop_sim_dense(h, dense.ctypes.data_as(C.POINTER(C.c_double))))
+                if n.value or rows.value:
+                    return names, dense, int(rows.value)
+        finally:
+            lib.impop_sim_free(h)
+    # fall back: exact reference behaviour (including its messages / sys.exit) for everything else
+    if flavor == "pica2":
+        d, elements, pair_count = read_similarity_file_pica2(filename)
+    else:
+        d, elements = read_similarity_file_hfst(filename)
+        pair_count = len(d)
+    names = sorted(elements)
+    return names, densify(d, names), pair_count

@@ -238,6 +238,24 @@ int impop_tajimas_d(impop_ctx *ctx, const int64_t *n, const double *S, const dou
 int impop_cluster_from_identity(impop_ctx *ctx, const double *ident, uint32_t n, double threshold,
                                 uint32_t *cluster_of, uint32_t *n_clusters, uint32_t *sizes);
 
+/* ---- native .sim ingest (host code) ------------------------------------------
+ * Replaces pica2.read_similarity_file (pica2.py:6-58) / h-fst.read_similarity_file
+ * (h-fst.py:84-119) for clean tab-separated files.  flavor 0 = pica2 (the first
+ * unparsable value stops the parse: bad_line / impop_sim_bad_text report it, the
+ * caller prints the reference's message and exits 1), flavor 1 = h-fst (unparsable
+ * values are skipped and counted in n_bad).  Returns IMPOP_E_UNSUPPORTED for any file
+ * shape it is not certain CPython's csv + float() would read identically (quotes,
+ * short rows, unusual number syntax, missing columns): the caller then uses the
+ * Python reader.  A missing file returns IMPOP_E_INVALID. */
+typedef struct impop_sim impop_sim;
+int impop_sim_parse(const char *path, int flavor, impop_sim **out);
+int impop_sim_info(const impop_sim *s, uint32_t *n_names, uint64_t *n_rows, uint64_t *names_bytes,
+                   int64_t *bad_line, uint64_t *n_bad);
+int impop_sim_names(const impop_sim *s, char *buf);          /* NUL-separated, sorted */
+int impop_sim_bad_text(const impop_sim *s, char *buf, size_t buflen);
+int impop_sim_dense(const impop_sim *s, double *out);        /* n x n, sorted-name order, NaN = absent */
+int impop_sim_free(impop_sim *s);
+
 /* CPython round(x, ndigits) (pica2.py:83, h-fst.py:150) evaluated on the GPU,
  * exposed so that the device implementation can be fuzzed against CPython. */
 int impop_py_round(impop_ctx *ctx, const double *x, uint64_t count, int ndigits, double *out);

@@ -6,7 +6,7 @@ import os
 import sys
 
 import _bootstrap  # noqa: F401
-from impop_amd.hfst import calculate_fst, expand_population, read_similarity_file, read_subset_file
+from impop_amd.hfst import calculate_fst_dense, expand_population, read_dense, read_subset_file
 
 
 def main():
@@ -22,7 +22,8 @@ def main():
 
     if args.verbose:
         print(f"Reading similarity file: {args.similarity_file}", file=sys.stderr)
-    similarities, all_sequences = read_similarity_file(args.similarity_file)
+    names, dense, _ = read_dense(args.similarity_file, "hfst")  # native ingest; reference messages on errors
+    all_sequences = set(names)
     if args.verbose:
         print("Reading population files...", file=sys.stderr)
     pop_a_raw = read_subset_file(args.pop_a)
@@ -45,8 +46,8 @@ def main():
     log_path = os.path.join(args.log_dir, f"{base_name}_fst.log")
     os.makedirs(args.log_dir, exist_ok=True)
     with open(log_path, 'w') as log_file:
-        results = calculate_fst(similarities, pop_a, pop_b, sequence_length=args.length, round_digits=args.round,
-                                log_file=log_file)
+        results = calculate_fst_dense(names, dense, pop_a, pop_b, sequence_length=args.length, round_digits=args.round,
+                                      log_file=log_file)
     print(f"{results['fst']:.8f}\t{results['pi_a']:.8f}\t{results['pi_b']:.8f}\t"
           f"{results['pi_xy']:.8f}\t{results['dxy']:.8f}\t{results['da']:.8f}")
     if args.verbose:

@@ -1,0 +1,132 @@
+#!/usr/bin/env python3
+"""Batch window driver: replaces the per-window `while read chr start end` loops of
+run_pica2_impg.sh:126-190, run_h-fst.sh:155-190 and run_tajd.sh:103-196 with ONE streaming GPU
+pass over a resident presence matrix, and prints the same TSV tables (headers
+run_pica2_impg.sh:119,122 / run_h-fst.sh:148 / run_tajd.sh:101) so plot_*_trend.R work unchanged.
+
+    impop_scan.py --matrix chr2.npz --bed windows.bed --format tajd -l samples.txt
+    impop_scan.py --matrix chr1.npz --bed windows.bed --format hfst -A afr.txt -B eas.txt
+    impop_scan.py --matrix chr2.npz --bed windows.bed --format pica2 [-u subset.txt] [-t 0.999 -r 5]
+
+--format pica2 with a threshold < 1 (or -r) needs the all-pairs path (impop_pairwise_scan);
+threshold >= 1 without rounding uses the streaming site-count scan.
+"""
+import argparse
+import os
+import sys
+
+import numpy as np
+
+import _bootstrap  # noqa: F401
+import impop_amd
+from impop_amd.matrixio import load_matrix
+from impop_amd.popnames import expand_population, read_subset_file
+
+
+def read_bed(path, contig_filter=None):
+    rows = []
+    with open(path) as f:
+        for line in f:
+            p = line.rstrip("\n").split("\t")
+            if not p or not p[0] or p[0].startswith("#"):
+                continue  # run_tajd.sh:104-106
+            if len(p) < 3 or not (p[1].isdigit() and p[2].isdigit()):
+                print(f"Warning: Skipping malformed BED entry: {' '.join(p[:3])}", file=sys.stderr)  # run_tajd.sh:108-111
+                continue
+            s, e = int(p[1]), int(p[2])
+            if e - s <= 0:
+                print(f"Warning: Skipping non-positive interval length for {p[0]}:{s}-{e}", file=sys.stderr)
+                continue
+            rows.append((p[0], s, e))
+    return rows
+
+
+def flags_for(list_file, names):
+    raw = read_subset_file(list_file)
+    members, missing = expand_population(raw, set(names))
+    if missing:
+        print(f"Warning: {len(missing)} identifiers from {os.path.basename(list_file)} did not match any sequences", file=sys.stderr)
+    return np.array([1 if n in members else 0 for n in names], dtype=np.uint8), raw
+
+
+def main():
+    ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
+    ap.add_argument("--matrix", required=True, help=".npz presence matrix (impop_amd.matrixio)")
+    ap.add_argument("--bed", "-b", required=True)
+    ap.add_argument("--format", choices=["pica2", "hfst", "tajd", "all"], default="all")
+    ap.add_argument("-A", "--pop-a"); ap.add_argument("-B", "--pop-b")
+    ap.add_argument("-l", "--sample-list", help="tajd: sample list (run_tajd.sh -l); n = its line count")
+    ap.add_argument("-u", "--subset", help="pica2: --subset-sequence-list")
+    ap.add_argument("-t", "--threshold", type=float, default=None)
+    ap.add_argument("-r", "--round-digits", type=int, default=None)
+    ap.add_argument("-p", "--region-prefix", default="CHM13#0#")
+    ap.add_argument("-o", "--output")
+    ap.add_argument("--identity", choices=["match", "dice"], default="match")
+    ap.add_argument("--device", type=int, default=0)
+    args = ap.parse_args()
+
+    mf = load_matrix(args.matrix)
+    names = mf.names
+    bed = read_bed(args.bed)
+    wins, regions = [], []
+    for chrom, s, e in bed:
+        b, en = mf.site_range(s, e)
+        wins.append((b, en, e - s))  # seq_len = LENGTH = end - start (run_pica2_impg.sh:133)
+        region = f"{chrom}:{s}-{e}" if chrom.startswith(args.region_prefix) else f"{args.region_prefix}{chrom}:{s}-{e}"
+        regions.append(region)
+    out = open(args.output, "w") if args.output else sys.stdout
+    ctx = impop_amd.Context(args.device)
+    need_pairwise = args.format == "pica2" and ((args.threshold is not None and args.threshold < 1.0) or args.round_digits is not None
+                                                 or args.identity != "match")
+    bm = ctx.upload(mf.bits, mf.n_site, keep_hap_major=need_pairwise)
+    mask_p = mask_a = mask_b = None
+    sample_count = mf.n_hap
+    if args.sample_list:
+        mask_p, raw = flags_for(args.sample_list, names)
+        sample_count = len(raw)  # run_tajd.sh:83: SAMPLE_COUNT = non-blank, non-# lines of the list
+    if args.subset:
+        mask_p, _ = flags_for(args.subset, names)
+    if args.pop_a and args.pop_b:
+        mask_a, _ = flags_for(args.pop_a, names)
+        mask_b, _ = flags_for(args.pop_b, names)
+        if not mask_a.any() or not mask_b.any():
+            print("Error: No valid sequences found in one or both populations", file=sys.stderr)  # h-fst.py:319-321
+            sys.exit(1)
+    if need_pairwise:
+        thr = 0.99 if args.threshold is None else args.threshold  # pica2.py:175 CLI default
+        res = bm.pairwise_scan(wins, mask_p, mask_a, mask_b, kind=args.identity, threshold=thr, round_digits=args.round_digits)
+    else:
+        res = bm.scan(wins, mask_p, mask_a, mask_b)
+    fmt = args.format
+    thr_txt = "1.0" if args.threshold is None and not need_pairwise else str(args.threshold if args.threshold is not None else 0.99)
+    r_txt = "" if args.round_digits is None else str(args.round_digits)
+    if fmt in ("pica2", "all"):
+        if args.subset:
+            print("REGION\tSUBSET\tLENGTH\tTHRESHOLD\tR_VALUE\tPICA_OUTPUT", file=out)
+        else:
+            print("REGION\tLENGTH\tTHRESHOLD\tR_VALUE\tPICA_OUTPUT", file=out)
+        for reg, (b, e, L), r in zip(regions, wins, res):
+            cell = f"{float(r['pi_site']):.8f} (sequence length: {L})"  # pica2.py:226
+            if args.subset:
+                print(f"{reg}\t{os.path.basename(args.subset)}\t{L}\t{thr_txt}\t{r_txt}\t{cell}", file=out)
+            else:
+                print(f"{reg}\t{L}\t{thr_txt}\t{r_txt}\t{cell}", file=out)
+    if fmt in ("hfst", "all") and mask_a is not None:
+        print("REGION\tLENGTH\tFST\tPI_A\tPI_B\tPI_XY\tDXY\tDA", file=out)
+        for reg, (b, e, L), r in zip(regions, wins, res):
+            print(f"{reg}\t{L}\t{float(r['fst']):.8f}\t{float(r['pi_a']):.8f}\t{float(r['pi_b']):.8f}\t"
+                  f"{float(r['pi_xy']):.8f}\t{float(r['dxy']):.8f}\t{float(r['da']):.8f}", file=out)
+    if fmt in ("tajd", "all"):
+        print("REGION\tLENGTH\tSAMPLES\tSEGREGATING_SITES\tPI\tTAJIMAS_D", file=out)
+        for reg, (b, e, L), r in zip(regions, wins, res):
+            D = float(r["tajima_d"])
+            taj = "NA" if D != D else repr(D)  # run_tajd.sh:192-194
+            print(f"{reg}\t{L}\t{sample_count}\t{int(r['s_all'])}\t{float(r['pi_site']):.8f}\t{taj}", file=out)
+    if args.output:
+        out.close()
+    bm.free()
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -5,7 +5,7 @@ import argparse
 import os
 
 import _bootstrap  # noqa: F401
-from impop_amd.pica2 import analyze_similarity_matrix, read_similarity_file
+from impop_amd.pica2 import analyze_dense, read_dense
 
 if __name__ == "__main__":
     parser = argparse.ArgumentParser(description='Analyze similarity matrix with customizable threshold and sequence length normalization')
@@ -21,7 +21,7 @@ if __name__ == "__main__":
     base_name = os.path.splitext(os.path.basename(args.input_file))[0]
     log_filename = os.path.join(args.log_dir, f"{base_name}.log")
     os.makedirs(args.log_dir, exist_ok=True)
-    similarity_dict, elements, pair_count = read_similarity_file(args.input_file)
+    names, dense, pair_count = read_dense(args.input_file, "pica2")  # native ingest; reference messages on errors
     with open(log_filename, 'w') as log_file:
         log_file.write("Nucleotide Diversity Analysis Log\n")
         log_file.write("=================================\n")
@@ -32,9 +32,9 @@ if __name__ == "__main__":
         if args.round_digits is not None:
             log_file.write(f"Similarity rounding: {args.round_digits} decimal places\n")
         log_file.write(f"Log file: {log_filename}\n\n")
-        pi, pi_per_site = analyze_similarity_matrix(similarity_dict, elements, pair_count, threshold=args.threshold,
-                                                    sequence_length=args.sequence_length, log_file=log_file,
-                                                    round_digits=args.round_digits)
+        pi, pi_per_site = analyze_dense(names, dense, pair_count, threshold=args.threshold,
+                                        sequence_length=args.sequence_length, log_file=log_file,
+                                        round_digits=args.round_digits)
         log_file.write("\n" + "=" * 50 + "\n")
         log_file.write("FINAL RESULTS:\n")
         log_file.write(f"pi = {pi:.6f}\n")

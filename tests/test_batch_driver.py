@@ -1,0 +1,63 @@
+"""GPU: scripts/impop_scan.py (the batch replacement of the run_*.sh window loops) prints the
+driver TSV schemas with the values the per-window reference chain would print (checked through
+the CPU oracle, which is pinned to the reference)."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def test_batch_driver_tables(tmp_path, oracle):
+    import impop_amd
+    from impop_amd import matrixio
+    rng = np.random.default_rng(12)
+    n, W = 24, 5000
+    anc = rng.integers(0, 2, size=W, dtype=np.uint8)
+    f = np.repeat(anc[None], 4, axis=0) ^ (rng.random((4, W)) < 0.01).astype(np.uint8)
+    m = f[rng.integers(0, 4, size=n)] ^ (rng.random((n, W)) < 0.002).astype(np.uint8)
+    names = [f"S{i // 2:03d}#{i % 2 + 1}#chr9:{1000}-{1000 + W}" for i in range(n)]
+    mf = matrixio.from_dense(m, names, origin=1000, contig="CHM13#0#chr9")
+    matrixio.save_matrix(str(tmp_path / "m.npz"), mf)
+    (tmp_path / "w.bed").write_text("# comment\nchr9\t1000\t3000\nchr9\t3000\t6000\nchr9\tx\ty\nCHM13#0#chr9\t2000\t2500\tname\n")
+    (tmp_path / "A.txt").write_text("S000\nS001_hap1_hprc_r2\nS002#2\n")
+    (tmp_path / "B.txt").write_text("S005\nS006\nS007_mat\n")
+    (tmp_path / "all.txt").write_text("\n".join(f"S{i:03d}" for i in range(12)) + "\n")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "impop_scan.py"), "--matrix", str(tmp_path / "m.npz"),
+                        "--bed", str(tmp_path / "w.bed"), "--format", "all", "-A", str(tmp_path / "A.txt"), "-B", str(tmp_path / "B.txt"),
+                        "-l", str(tmp_path / "all.txt")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    lines = r.stdout.strip().split("\n")
+    assert lines[0] == "REGION\tLENGTH\tTHRESHOLD\tR_VALUE\tPICA_OUTPUT"       # run_pica2_impg.sh:122
+    assert lines[4] == "REGION\tLENGTH\tFST\tPI_A\tPI_B\tPI_XY\tDXY\tDA"          # run_h-fst.sh:148
+    assert lines[8] == "REGION\tLENGTH\tSAMPLES\tSEGREGATING_SITES\tPI\tTAJIMAS_D"  # run_tajd.sh:101
+    assert "Skipping malformed BED entry" in r.stderr
+    inA = np.array([1 if nm.startswith(("S000#", "S001#1#", "S002#2#")) else 0 for nm in names], np.uint8)
+    inB = np.array([1 if nm.startswith(("S005#", "S006#", "S007#1#")) else 0 for nm in names], np.uint8)
+    bits = oracle.pack_hap_major(m)
+    ones = oracle.pack_mask(np.ones(n, np.uint8))
+    wins = [(0, 2000, 2000, "CHM13#0#chr9:1000-3000"), (2000, 5000, 3000, "CHM13#0#chr9:3000-6000"), (1000, 1500, 500, "CHM13#0#chr9:2000-2500")]
+    for k, (s0, s1, L, reg) in enumerate(wins):
+        w = oracle.window_allpairs(bits, n, s0, s1, ones, oracle.pack_mask(inA), oracle.pack_mask(inB), L)
+        assert lines[1 + k] == f"{reg}\t{L}\t1.0\t\t{w['pi_site']:.8f} (sequence length: {L})"
+        assert lines[5 + k] == (f"{reg}\t{L}\t{w['fst']:.8f}\t{w['pi_a']:.8f}\t{w['pi_b']:.8f}\t{w['pi_xy']:.8f}\t"
+                                f"{w['dxy']:.8f}\t{w['da']:.8f}")
+        t = lines[9 + k].split("\t")
+        assert t[:5] == [reg, str(L), "12", str(w["s_all"]), f"{w['pi_site']:.8f}"]
+        # D is printed with repr(); n = 12 list lines (run_tajd.sh:83) => recompute through the oracle
+        D, _ = oracle.tajimas_d(n, float(w["s_all"]), oracle.py_round(w["pi_site"], 8))
+        assert abs(float(t[5]) - D) <= 1e-9 * abs(D)
+    # thresholded pica2 goes through the all-pairs path
+    r2 = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "impop_scan.py"), "--matrix", str(tmp_path / "m.npz"),
+                         "--bed", str(tmp_path / "w.bed"), "--format", "pica2", "-t", "0.995", "-r", "4"], capture_output=True, text=True)
+    assert r2.returncode == 0, r2.stderr
+    l2 = r2.stdout.strip().split("\n")
+    for k, (s0, s1, L, reg) in enumerate(wins):
+        sim = oracle.identity(oracle.pairwise_counts(bits, n, s0, s1), s1 - s0, 0)
+        pi, ps, _, _ = oracle.pica2(sim, 0.995, L, 4)
+        assert l2[1 + k] == f"{reg}\t{L}\t0.995\t4\t{ps:.8f} (sequence length: {L})"

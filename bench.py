@@ -128,11 +128,19 @@ def main():
     if not torch.cuda.is_available():
         log("bench.py: no GPU visible; impop_amd has no CPU path to measure")
         sys.exit(2)
+    # IMPOP_BENCH_BACKEND=gloo is a REHEARSAL mode only (several ranks on one GPU, records staged
+    # through the host); the measured configuration is one rank per GPU over RCCL ("nccl").
+    backend = os.environ.get("IMPOP_BENCH_BACKEND", "nccl")
+    if backend == "gloo":
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     stream = torch.cuda.current_stream(dev)
     ctx = impop_amd.Context(local_rank, stream=stream.cuda_stream)
@@ -149,12 +157,13 @@ def main():
     in_b = np.zeros(n, np.uint8); in_b[min(140, n): min(240, n)] = 1
     plan = bm.plan(windows, None, in_a, in_b, tile_blocks=args.tile_blocks)
     local = torch.empty(NW * 128, dtype=torch.uint8, device=dev)
-    gathered = torch.empty(world * NW * 128, dtype=torch.uint8, device=dev) if world > 1 else None
+    gdev = dev if backend == "nccl" else torch.device("cpu")
+    gathered = torch.empty(world * NW * 128, dtype=torch.uint8, device=gdev) if world > 1 else None
 
     def step():
         plan.launch(local.data_ptr())
         if world > 1:
-            dist.all_gather_into_tensor(gathered, local)
+            dist.all_gather_into_tensor(gathered, local if backend == "nccl" else local.cpu())
 
     # ---- parity gate before timing (rank 0): GPU records vs the CPU oracle on sampled windows
     step()
@@ -195,10 +204,10 @@ def main():
     kern_ms, launches = plan.elapsed()
     plan.timing(False)
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=gdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        k = torch.tensor([kern_ms], dtype=torch.float64, device=dev)
+        k = torch.tensor([kern_ms], dtype=torch.float64, device=gdev)
         dist.all_reduce(k, op=dist.ReduceOp.MAX)
         kern_ms = float(k.item())
 

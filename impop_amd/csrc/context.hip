@@ -39,22 +39,6 @@ int ctx_scratch(impop_ctx *ctx, size_t bytes, void **out) {
     return IMPOP_OK;
 }
 
-int ctx_pinned(impop_ctx *ctx, size_t bytes, void **out) {
-    if (bytes > ctx->pinned_bytes) {
-        if (ctx->pinned) {
-            HIP_TRY(hipStreamSynchronize(ctx->stream));
-            HIP_TRY(hipHostFree(ctx->pinned));
-            ctx->pinned = nullptr;
-            ctx->pinned_bytes = 0;
-        }
-        size_t want = bytes + (bytes >> 2) + 4096;
-        HIP_TRY(hipHostMalloc(&ctx->pinned, want, hipHostMallocDefault));
-        ctx->pinned_bytes = want;
-    }
-    *out = ctx->pinned;
-    return IMPOP_OK;
-}
-
 __global__ void tajima_consts_kernel(int64_t n, double *out) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
         TajConsts c = tajima_consts(n);
@@ -137,7 +121,6 @@ IMPOP_API int impop_ctx_destroy(impop_ctx *ctx) {
     hipStreamSynchronize(ctx->stream);
     if (ctx->d_taj) hipFree(ctx->d_taj);
     if (ctx->scratch) hipFree(ctx->scratch);
-    if (ctx->pinned) hipHostFree(ctx->pinned);
     if (ctx->own_stream) hipStreamDestroy(ctx->stream);
     delete ctx;
     return IMPOP_OK;

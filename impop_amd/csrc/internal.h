@@ -62,8 +62,6 @@ struct impop_ctx {
     // growable scratch
     void *scratch = nullptr;
     size_t scratch_bytes = 0;
-    void *pinned = nullptr;
-    size_t pinned_bytes = 0;
 };
 
 struct impop_matrix {
@@ -83,7 +81,6 @@ struct impop_matrix {
 
 namespace impop {
 int ctx_scratch(impop_ctx *ctx, size_t bytes, void **out);
-int ctx_pinned(impop_ctx *ctx, size_t bytes, void **out);
 int ensure_tajima_consts(impop_ctx *ctx, int64_t n);  // fills ctx->d_taj for n (device kernel)
 
 // layout.hip
@@ -92,14 +89,4 @@ int launch_hm_to_sb(impop_ctx *ctx, const uint32_t *d_hm, uint64_t hm_stride, co
 int launch_sb_to_hm(impop_ctx *ctx, const uint32_t *d_sb, const SbGeom &g, uint64_t blk_begin, uint64_t blk_end,
                     uint32_t *d_hm, uint64_t hm_stride, uint32_t n_rows, uint64_t rb_nq = 0);
 
-// stats.hip — "problem" = one identity matrix (dense or derived from Gram counts)
-struct SimSource {
-    const double *dense;    // n x ld doubles (NaN = missing) or nullptr
-    const int32_t *gram;    // ldg x ldg int32 intersection counts (upper tiles valid, see pairwise.hip)
-    uint32_t ld;            // leading dimension of dense / gram
-    uint32_t n;             // number of elements in the full matrix
-    uint64_t W;             // sites in the window (gram mode)
-    int kind;               // IMPOP_IDENTITY_*
-    int round_digits;       // <0 none
-};
 }  // namespace impop

@@ -44,7 +44,6 @@ __global__ __launch_bounds__(ST) void pica2_kernel(SimBatch batch, const uint32_
     uint32_t *grp = reinterpret_cast<uint32_t *>(rowsum + n_el);
     uint32_t *rep = grp + n_el;
     uint32_t *gsz = rep + n_el;
-    __shared__ double shd[ST / 64];
     __shared__ uint32_t sh_have;
     const uint64_t prob = blockIdx.x;
     const SimView S = sim_view(batch, prob);
@@ -102,7 +101,6 @@ __global__ __launch_bounds__(ST) void pica2_kernel(SimBatch batch, const uint32_
     }
     if (group_of)
         for (uint32_t i = tid; i < n_el; i += ST) group_of[prob * n_el + i] = grp[i];
-    (void)shd;
 }
 
 // ---------------------------------------------------------------------------------------

@@ -338,3 +338,44 @@ def test_full_size_window_properties(ctx):
     assert ((a["fst"] >= -1) & (a["fst"] <= 1)).all() and (a["pi"] > 0).all() and (a["pi"] < 0.5).all()
     assert (a["tajima_d"] < 0).all()  # excess of rare variants by construction
     bm.free()
+
+
+def test_config5_shape_4096_haplotypes(ctx, oracle):
+    """BASELINE config 5 shape (4096 haplotypes) at a size the oracle finishes in seconds: the
+    generic (wps = 128) scan kernel and the K-split int8-MFMA Gram kernel, integers bit-exact."""
+    import impop_amd
+    n, W = 4096, 6000
+    bm = ctx.synthetic(n, W, seed=5, n_founder=16, p_founder=0.05, p_private_word=0.05, keep_hap_major=True)
+    bits = bm.download()
+    m = impop_amd.unpack_hap_major(bits, W)
+    rng = np.random.default_rng(4096)
+    inA = (rng.random(n) < 0.3).astype(np.uint8)
+    inB = ((rng.random(n) < 0.3) & (inA == 0)).astype(np.uint8)
+    wins = [(0, W, W), (100, 4133, 50000), (5999, 6000, 1)]
+    got = bm.scan(wins, None, inA, inB)
+    ones = oracle.pack_mask(np.ones(n, np.uint8))
+    for (s0, s1, sl), r in zip(wins, got):
+        want = oracle.window_sitecount(bits, n, s0, s1, ones, oracle.pack_mask(inA), oracle.pack_mask(inB), sl)
+        check_record(r, want, ("n4096", s0, s1))
+    # Gram: full matrix against numpy int64 (exact), one unaligned window
+    I = bm.pairwise_counts(37, 5901)
+    mm = m[:, 37:5901].astype(np.int32)
+    want = (mm @ mm.T).astype(np.int64)
+    assert (I.astype(np.int64) == want).all()
+    bm.free()
+
+
+def test_gram_determinism_and_batch(ctx):
+    """K-split partial sums are integer atomics: two runs must be bit-identical; a batch of windows
+    (grouped XCD mapping, >= 8 windows) equals the same windows run one by one."""
+    n, W = 465, 64 * 300
+    bm = ctx.synthetic(n, W, seed=99, keep_hap_major=True)
+    a = bm.pairwise_counts(5, W - 3)
+    b = bm.pairwise_counts(5, W - 3)
+    assert (a == b).all()
+    wins = [(i * 1500, i * 1500 + 1400 + i, 1500) for i in range(11)]
+    res = bm.pairwise_scan(wins, None, None, None, kind="dice", threshold=0.9995, round_digits=None)
+    for w, r in zip(wins, res):
+        one = bm.pairwise_scan([w], None, None, None, kind="dice", threshold=0.9995, round_digits=None)[0]
+        assert r.tobytes() == one.tobytes()
+    bm.free()

@@ -89,8 +89,25 @@ def cpu_baseline(bm, windows, in_a, in_b, budget_s=12.0):
         t_sc += time.perf_counter() - t0
         n_sc += 1
         j += 1
+    # reference-STYLE chain (TSV text -> csv.DictReader -> dict algorithms), pure Python, 2 windows
+    from oracle import ref_style
+    t_py, n_py, py_rec = 0.0, 0, None
+    names = [f"H{i // 2:05d}#{i % 2 + 1}#chr2:0-{int(windows[0]['seq_len'])}" for i in range(n)]
+    for wi in range(min(2, len(windows))):
+        w = windows[wi]
+        s0, s1 = int(w["site_begin"]), int(w["site_end"])
+        bits = bm.download(s0, s1)
+        sim = orc.identity(orc.pairwise_counts(bits, n, 0, s1 - s0), s1 - s0, 0)  # what `impg similarity` would hand over (not timed)
+        S = orc.window_sitecount(bits, n, 0, s1 - s0, ones, ma, mb, int(w["seq_len"]))["s_all"]
+        t0 = time.perf_counter()
+        py_rec = ref_style.window_chain(names, sim, in_a, in_b, int(w["seq_len"]), S)
+        t_py += time.perf_counter() - t0
+        n_py += 1
     return {
         "value": n_all / t_all if t_all > 0 else None, "unit": "windows/s", "cores": 1, "kind": "port",
+        "reference_style_python": {"value": n_py / t_py if t_py > 0 else None, "unit": "windows/s", "cores": 1,
+                                   "sample": f"{n_py} windows: identity table -> .sim text -> csv.DictReader -> dict algorithms "
+                                             f"(oracle/ref_style.py, CPython, {t_py:.1f} s)"},
         "sample": f"first {n_all} windows of the timed workload through oracle_window_allpairs "
                   f"(all-pairs Hamming + pica2/h-fst/tj_d restatement, gcc -O2, 1 thread, {t_all:.1f} s)",
         "sitecount_port": {"value": n_sc / t_sc if t_sc > 0 else None, "unit": "windows/s", "cores": 1,

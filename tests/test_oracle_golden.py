@@ -160,3 +160,20 @@ def test_ragged_and_degenerate(oracle):
         assert cnt[5] == 2  # two between-pairs missing
     assert oracle.pica2(np.zeros((0, 0)), 1.0, 100)[:2] == (fh(g["degenerate"]["empty"][0]), fh(g["degenerate"]["empty"][1]))
     assert oracle.pica2(np.ones((1, 1)), 1.0, 100)[:2] == (fh(g["degenerate"]["single"][0]), fh(g["degenerate"]["single"][1]))
+
+
+def test_ref_style_python_chain_matches_oracle(oracle):
+    """oracle/ref_style.py (the pure-Python, dict-based timing path of bench.py) against the C oracle."""
+    from oracle import ref_style
+    g = load_golden("bitmatrix.json")
+    m = g["matrices"][1]
+    n, W, L = m["n"], m["W"], m["L"]
+    bits = golden_bits(m)
+    sim = oracle.identity(oracle.pairwise_counts(bits, n, 0, W), W, 0)
+    inA, inB = np.array(m["in_a"], np.uint8), np.array(m["in_b"], np.uint8)
+    ones = oracle.pack_mask(np.ones(n, np.uint8))
+    want = oracle.window_allpairs(bits, n, 0, W, ones, oracle.pack_mask(inA), oracle.pack_mask(inB), L)
+    got = ref_style.window_chain(m["names"], sim, inA, inB, L, want["s_all"])
+    for k in ("pi", "pi_site", "pi_a", "pi_b", "pi_xy", "dxy", "da", "fst", "tajima_d"):
+        assert rel_close(got[k], want[k], 1e-12, 1e-18), (k, got[k], want[k])
+    assert rel_close(got["tajima_d"], fh(m["tajd_chain"]["D"]), 1e-12)

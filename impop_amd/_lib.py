@@ -49,6 +49,11 @@ class SynthParams(C.Structure):
                 ("p_private_word", C.c_double)]
 
 
+class PairStats(C.Structure):
+    _fields_ = [("fst", C.c_double), ("pi_a", C.c_double), ("pi_b", C.c_double), ("pi_xy", C.c_double),
+                ("dxy", C.c_double), ("da", C.c_double)]
+
+
 class PairwiseParams(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("identity_kind", C.c_int32), ("threshold", C.c_double),
                 ("round_digits", C.c_int32), ("d_pi_mode", C.c_int32), ("s_scope", C.c_int32),
@@ -96,6 +101,8 @@ SIGNATURES = {
     "impop_scan_plan_destroy": (C.c_int, [_vp]),
     "impop_scan": (C.c_int, [_vp, _vp, C.POINTER(Window), C.c_uint64, _u64p, _u64p, _u64p, C.POINTER(ScanParams),
                              C.POINTER(WindowStats)]),
+    "impop_scan_multi": (C.c_int, [_vp, _vp, C.POINTER(Window), C.c_uint64, _u64p, C.c_uint32, C.POINTER(PairStats)]),
+    "impop_afs": (C.c_int, [_vp, _vp, C.POINTER(Window), C.c_uint64, _u64p, _u32p]),
     "impop_site_counts": (C.c_int, [_vp, _vp, _u64p, C.c_uint64, C.c_uint64, _u32p]),
     "impop_pairwise_counts": (C.c_int, [_vp, _vp, C.c_uint64, C.c_uint64, _i32p]),
     "impop_pairwise_identity": (C.c_int, [_vp, _vp, C.c_uint64, C.c_uint64, C.c_int, _f64p]),

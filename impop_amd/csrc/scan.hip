@@ -292,6 +292,131 @@ __global__ __launch_bounds__(256) void site_counts_kernel(const uint32_t *__rest
     out[s - site_begin] = c;
 }
 
+// ---- K disjoint populations in one pass: all-pairs Hudson Fst (run_h_fst_panels.sh:60-71) -------
+// Per tile: sum_k c_k (n_k - c_k) for every population and sum_s [c_k (n_l - c_l) + c_l (n_k - c_k)] for
+// every pair k < l.  Masks come from memory (wave-uniform scalar loads); K is a template parameter so
+// that the per-lane accumulators are registers.  out: tile-major, K + K(K-1)/2 uint64 per tile.
+template <int K>
+__global__ __launch_bounds__(256) void scan_multi_kernel(const uint32_t *__restrict__ sb, const ScanTile *__restrict__ tiles,
+                                                         const uint32_t *__restrict__ masks /* K x wps */,
+                                                         const uint32_t *__restrict__ pop_n /* K */, uint32_t wps,
+                                                         uint32_t G, uint32_t r, uint64_t *__restrict__ out) {
+    constexpr int NP = K * (K - 1) / 2;
+    __shared__ uint64_t red[4][K + NP];
+    const ScanTile t = tiles[blockIdx.x];
+    const uint64_t b0 = t.site_begin >> 6, b1 = (t.site_end + 63) >> 6;
+    const uint32_t lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    uint32_t nk[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) nk[k] = pop_n[k];
+    uint64_t acc[K + NP];
+#pragma unroll
+    for (int i = 0; i < K + NP; ++i) acc[i] = 0;
+    for (uint64_t b = b0 + wave; b < b1; b += 4) {
+        const uint32_t *blk = sb + b * 64ull * wps;
+        uint32_t c[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) c[k] = 0;
+        for (uint32_t g = 0; g + 1 < G; ++g) {
+            const u32v4 v = stream_load(reinterpret_cast<const u32v4 *>(blk + (uint64_t)g * 256 + lane * 4));
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                const uint32_t *mk = masks + (uint64_t)k * wps + 4 * g;
+                c[k] += __popc(v.x & mk[0]) + __popc(v.y & mk[1]) + __popc(v.z & mk[2]) + __popc(v.w & mk[3]);
+            }
+        }
+        const uint32_t *last = blk + (uint64_t)(G - 1) * 256 + lane * r;
+        for (uint32_t j = 0; j < r; ++j) {
+            const uint32_t v = stream_load(last + j);
+#pragma unroll
+            for (int k = 0; k < K; ++k) c[k] += __popc(v & masks[(uint64_t)k * wps + 4 * (G - 1) + j]);
+        }
+        const uint64_t s = b * 64 + lane;
+        if (s >= t.site_begin && s < t.site_end) {
+            int pi = K;
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                acc[k] += c[k] * (nk[k] - c[k]);
+#pragma unroll
+                for (int l = k + 1; l < K; ++l) acc[pi++] += c[k] * (nk[l] - c[l]) + c[l] * (nk[k] - c[k]);
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < K + NP; ++i) {
+        const uint64_t v = wave_sum_u64(acc[i]);
+        if (lane == 0) red[wave][i] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < K + NP)
+        out[(uint64_t)blockIdx.x * (K + NP) + threadIdx.x] =
+            red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+
+// one thread per (window, pair): h-fst.py:203-240 on the exact pair sums
+__global__ void scan_multi_finalize_kernel(const uint64_t *__restrict__ parts, const WinDesc *__restrict__ wins,
+                                           uint64_t n_windows, uint32_t K, const uint32_t *__restrict__ pop_n,
+                                           impop_pair_stats *__restrict__ out) {
+    const uint32_t NP = K * (K - 1) / 2, stride = K + NP;
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_windows * NP) return;
+    const uint64_t win = i / NP;
+    uint32_t p = (uint32_t)(i % NP), k = 0;
+    while (p >= K - 1 - k) { p -= K - 1 - k; ++k; }
+    const uint32_t l = k + 1 + p;
+    const WinDesc w = wins[win];
+    uint64_t sk = 0, sl = 0, skl = 0;
+    for (uint64_t t = w.t0; t < w.t1; ++t) {
+        sk += parts[t * stride + k];
+        sl += parts[t * stride + l];
+        skl += parts[t * stride + K + (uint32_t)(i % NP)];
+    }
+    const double W = (double)w.n_sites, seq_len = (double)w.seq_len;
+    const double nA = (double)pop_n[k], nB = (double)pop_n[l];
+    const double pairsA = nA * (nA - 1.0) / 2.0, pairsB = nB * (nB - 1.0) / 2.0;
+    double pi_a = (pop_n[k] >= 2 && W > 0) ? (double)sk / (pairsA * W) : 0.0;
+    double pi_b = (pop_n[l] >= 2 && W > 0) ? (double)sl / (pairsB * W) : 0.0;
+    double dxy = (pop_n[k] && pop_n[l] && W > 0) ? (double)skl / (nA * nB * W) : 0.0;
+    double pi_xy = 0.5 * (pi_a + pi_b);
+    const double fst = (dxy > 0) ? (dxy - pi_xy) / dxy : 0.0;
+    double da = dxy - pi_xy;
+    if (seq_len > 0) { pi_a /= seq_len; pi_b /= seq_len; da = (dxy - pi_xy) / seq_len; pi_xy /= seq_len; dxy /= seq_len; }
+    impop_pair_stats r;
+    r.fst = fst; r.pi_a = pi_a; r.pi_b = pi_b; r.pi_xy = pi_xy; r.dxy = dxy; r.da = da;
+    out[i] = r;
+}
+
+// ---- allele-frequency spectrum (scripts/wip/op-afs.py): per window, how many sites carry c copies ----
+// grid (chunks of 4096 sites, windows); LDS histogram per workgroup, integer atomics to the output.
+__global__ __launch_bounds__(256) void afs_kernel(const uint32_t *__restrict__ sb, const uint32_t *__restrict__ mask,
+                                                  uint32_t wps, uint32_t G, uint32_t r, const impop_window *__restrict__ wins,
+                                                  uint32_t bins, uint32_t *__restrict__ out) {
+    extern __shared__ uint32_t hist[];
+    const impop_window w = wins[blockIdx.y];
+    const uint64_t c0 = w.site_begin + (uint64_t)blockIdx.x * 4096;
+    if (c0 >= w.site_end) return;  // uniform per workgroup
+    const uint64_t c1 = c0 + 4096 < w.site_end ? c0 + 4096 : w.site_end;
+    for (uint32_t i = threadIdx.x; i < bins; i += 256) hist[i] = 0;
+    __syncthreads();
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (uint64_t b = (c0 >> 6) + wave; b <= ((c1 - 1) >> 6); b += 4) {
+        const uint64_t s = b * 64 + lane;
+        if (s < c0 || s >= c1) continue;
+        const uint32_t *blk = sb + b * 64ull * wps;
+        uint32_t c = 0;
+        for (uint32_t k = 0; k < wps; ++k) {
+            const uint32_t g = k >> 2;
+            const uint32_t v = (g + 1 < G) ? blk[(uint64_t)g * 256 + lane * 4 + (k & 3)]
+                                           : blk[(uint64_t)(G - 1) * 256 + lane * r + (k - 4 * (G - 1))];
+            c += __popc(v & mask[k]);
+        }
+        atomicAdd(&hist[c], 1u);
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < bins; i += 256)
+        if (hist[i]) atomicAdd(&out[(uint64_t)blockIdx.y * bins + i], hist[i]);
+}
+
 // mask bitset (uint64 words, n bits) -> wps dwords clipped to n; NULL -> `fill`
 static void mask_to_dwords(const uint64_t *mask, uint32_t n, uint32_t wps, bool fill_all, std::vector<uint32_t> &out) {
     out.assign(wps, 0u);
@@ -308,6 +433,60 @@ static uint32_t popcount_vec(const std::vector<uint32_t> &v) {
     uint32_t c = 0;
     for (uint32_t x : v) c += (uint32_t)__builtin_popcount(x);
     return c;
+}
+
+// windows -> elementary segments between sorted window boundaries (a segment is tiled iff some
+// window covers it, and exactly once however many windows overlap it) -> tiles of <= tile_blocks
+// 64-site blocks; every window becomes a contiguous tile range [t0, t1).
+static void build_tiles(const impop_window *windows, uint64_t n_windows, uint32_t tile_blocks, uint32_t wps,
+                        std::vector<ScanTile> &tiles, std::vector<WinDesc> &wd, uint64_t &bytes_streamed) {
+    std::vector<uint64_t> cuts;
+    cuts.reserve(2 * n_windows);
+    for (uint64_t i = 0; i < n_windows; ++i)
+        if (windows[i].site_end > windows[i].site_begin) {
+            cuts.push_back(windows[i].site_begin);
+            cuts.push_back(windows[i].site_end);
+        }
+    std::sort(cuts.begin(), cuts.end());
+    cuts.erase(std::unique(cuts.begin(), cuts.end()), cuts.end());
+    std::vector<int64_t> cover(cuts.size() + 1, 0);
+    auto cut_index = [&](uint64_t s) { return (size_t)(std::lower_bound(cuts.begin(), cuts.end(), s) - cuts.begin()); };
+    for (uint64_t i = 0; i < n_windows; ++i)
+        if (windows[i].site_end > windows[i].site_begin) {
+            cover[cut_index(windows[i].site_begin)] += 1;
+            cover[cut_index(windows[i].site_end)] -= 1;
+        }
+    std::vector<uint64_t> seg_tile_start(cuts.size() + 1, 0);
+    int64_t depth = 0;
+    for (size_t k = 0; k + 1 < cuts.size(); ++k) {
+        seg_tile_start[k] = tiles.size();
+        depth += cover[k];
+        if (depth <= 0) continue;
+        // tiles are cut on 64-site block boundaries of the matrix so interior tiles read whole blocks
+        uint64_t s = cuts[k];
+        const uint64_t e = cuts[k + 1];
+        while (s < e) {
+            uint64_t t_end = ((s / 64) + tile_blocks) * 64;  // block-aligned end
+            if (t_end > e) t_end = e;
+            tiles.push_back({s, t_end});
+            bytes_streamed += ((t_end + 63) / 64 - s / 64) * 64ull * wps * 4ull;
+            s = t_end;
+        }
+    }
+    if (!cuts.empty()) seg_tile_start[cuts.size() - 1] = tiles.size();
+    seg_tile_start[cuts.size()] = tiles.size();
+    wd.resize(n_windows);
+    for (uint64_t i = 0; i < n_windows; ++i) {
+        WinDesc &w = wd[i];
+        w.n_sites = windows[i].site_end - windows[i].site_begin;
+        w.seq_len = windows[i].seq_len;
+        if (w.n_sites) {
+            w.t0 = seg_tile_start[cut_index(windows[i].site_begin)];
+            w.t1 = seg_tile_start[cut_index(windows[i].site_end)];
+        } else {
+            w.t0 = w.t1 = 0;
+        }
+    }
 }
 
 }  // namespace impop
@@ -397,57 +576,9 @@ IMPOP_API int impop_scan_plan_create(impop_ctx *ctx, const impop_matrix *m, cons
     p->masks.insert(p->masks.end(), ma.begin(), ma.end());
     p->masks.insert(p->masks.end(), mb.begin(), mb.end());
 
-    // elementary segments between sorted window boundaries; a segment is tiled iff some window covers it
-    std::vector<uint64_t> cuts;
-    cuts.reserve(2 * n_windows);
-    for (uint64_t i = 0; i < n_windows; ++i)
-        if (windows[i].site_end > windows[i].site_begin) {
-            cuts.push_back(windows[i].site_begin);
-            cuts.push_back(windows[i].site_end);
-        }
-    std::sort(cuts.begin(), cuts.end());
-    cuts.erase(std::unique(cuts.begin(), cuts.end()), cuts.end());
-    std::vector<int64_t> cover(cuts.size() + 1, 0);
-    auto cut_index = [&](uint64_t s) { return (size_t)(std::lower_bound(cuts.begin(), cuts.end(), s) - cuts.begin()); };
-    for (uint64_t i = 0; i < n_windows; ++i)
-        if (windows[i].site_end > windows[i].site_begin) {
-            cover[cut_index(windows[i].site_begin)] += 1;
-            cover[cut_index(windows[i].site_end)] -= 1;
-        }
     std::vector<ScanTile> tiles;
-    std::vector<uint64_t> seg_tile_start(cuts.size() + 1, 0);
-    int64_t depth = 0;
-    const uint64_t tile_sites = (uint64_t)tile_blocks * 64;
-    for (size_t k = 0; k + 1 < cuts.size(); ++k) {
-        seg_tile_start[k] = tiles.size();
-        depth += cover[k];
-        if (depth <= 0) continue;
-        // tiles are cut on 64-site block boundaries of the matrix so interior tiles read whole blocks
-        uint64_t s = cuts[k];
-        const uint64_t e = cuts[k + 1];
-        while (s < e) {
-            uint64_t t_end = ((s / 64) + tile_blocks) * 64;  // block-aligned end
-            if (t_end > e) t_end = e;
-            tiles.push_back({s, t_end});
-            p->bytes_streamed += ((t_end + 63) / 64 - s / 64) * 64ull * wps * 4ull;
-            s = t_end;
-        }
-    }
-    (void)tile_sites;
-    if (!cuts.empty()) seg_tile_start[cuts.size() - 1] = tiles.size();
-    seg_tile_start[cuts.size()] = tiles.size();
-    std::vector<WinDesc> wd(n_windows);
-    for (uint64_t i = 0; i < n_windows; ++i) {
-        WinDesc &w = wd[i];
-        w.n_sites = windows[i].site_end - windows[i].site_begin;
-        w.seq_len = windows[i].seq_len;
-        if (w.n_sites) {
-            w.t0 = seg_tile_start[cut_index(windows[i].site_begin)];
-            w.t1 = seg_tile_start[cut_index(windows[i].site_end)];
-        } else {
-            w.t0 = w.t1 = 0;
-        }
-    }
+    std::vector<WinDesc> wd;
+    build_tiles(windows, n_windows, tile_blocks, wps, tiles, wd, p->bytes_streamed);
     p->n_tiles = tiles.size();
     auto fail = [&](int code) {
         impop_scan_plan_destroy(p);
@@ -607,6 +738,125 @@ IMPOP_API int impop_site_counts(impop_ctx *ctx, const impop_matrix *m, const uin
                        m->g.wps, m->g.G, m->g.r, site_begin, site_end, d_cnt);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(out_host, d_cnt, W * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return IMPOP_OK;
+}
+
+template <int K>
+static void launch_multi(hipStream_t st, const impop_matrix *m, uint64_t n_tiles, const ScanTile *d_tiles, const uint32_t *d_masks,
+                         const uint32_t *d_n, uint64_t *d_parts) {
+    hipLaunchKernelGGL((scan_multi_kernel<K>), dim3((uint32_t)n_tiles), dim3(256), 0, st, m->d_sb, d_tiles, d_masks, d_n, m->g.wps,
+                       m->g.G, m->g.r, d_parts);
+}
+
+IMPOP_API int impop_scan_multi(impop_ctx *ctx, const impop_matrix *m, const impop_window *windows, uint64_t n_windows,
+                               const uint64_t *masks, uint32_t n_pop, impop_pair_stats *out_host) {
+    REQUIRE(ctx && m, "impop_scan_multi: NULL argument");
+    REQUIRE(n_pop >= 2 && n_pop <= 8, "impop_scan_multi: n_pop must be 2..8");
+    REQUIRE(masks, "impop_scan_multi: masks is NULL");
+    REQUIRE(m->g.n_hap <= 65535, "impop_scan_multi: n_hap > 65535 not supported");
+    if (!n_windows) return IMPOP_OK;
+    REQUIRE(windows && out_host, "impop_scan_multi: NULL windows/out");
+    for (uint64_t i = 0; i < n_windows; ++i)
+        REQUIRE(windows[i].site_begin <= windows[i].site_end && windows[i].site_end <= m->g.n_site &&
+                    windows[i].site_end - windows[i].site_begin <= 0xFFFFFFFFull,
+                "impop_scan_multi: window %llu: bad site range", (unsigned long long)i);
+    const uint32_t n = m->g.n_hap, wps = m->g.wps, K = n_pop, NP = K * (K - 1) / 2;
+    const uint32_t mwords = (n + 63) / 64;
+    std::vector<uint32_t> mk((size_t)K * wps), nk(K);
+    std::vector<uint32_t> seen(wps, 0u), one;
+    for (uint32_t k = 0; k < K; ++k) {
+        mask_to_dwords(masks + (size_t)k * mwords, n, wps, false, one);
+        for (uint32_t j = 0; j < wps; ++j) {
+            // h-fst.py:181-185 removes shared members per pair; with K populations that would make
+            // n_k pair-dependent, so the one-pass form requires disjoint populations
+            REQUIRE((seen[j] & one[j]) == 0, "impop_scan_multi: populations must be disjoint (population %u overlaps an earlier one)", k);
+            seen[j] |= one[j];
+            mk[(size_t)k * wps + j] = one[j];
+        }
+        nk[k] = popcount_vec(one);
+    }
+    HIP_TRY(hipSetDevice(ctx->device));
+    std::vector<ScanTile> tiles;
+    std::vector<WinDesc> wd;
+    uint64_t bytes = 0;
+    build_tiles(windows, n_windows, 32, wps, tiles, wd, bytes);
+    REQUIRE(tiles.size() < 0x7FFFFFFFull, "impop_scan_multi: too many tiles");
+    const size_t nt = tiles.size();
+    auto up = [](size_t x) { return (x + 255) / 256 * 256; };
+    const size_t o_tiles = 0, o_wins = o_tiles + up(std::max<size_t>(nt, 1) * sizeof(ScanTile)),
+                 o_masks = o_wins + up(n_windows * sizeof(WinDesc)), o_n = o_masks + up(mk.size() * 4),
+                 o_parts = o_n + up(K * 4), o_out = o_parts + up(std::max<size_t>(nt, 1) * (K + NP) * 8),
+                 total = o_out + up(n_windows * NP * sizeof(impop_pair_stats));
+    void *d = nullptr;
+    int rc = ctx_scratch(ctx, total, &d);
+    if (rc) return rc;
+    char *base = (char *)d;
+    if (nt) HIP_TRY(hipMemcpyAsync(base + o_tiles, tiles.data(), nt * sizeof(ScanTile), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(base + o_wins, wd.data(), n_windows * sizeof(WinDesc), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(base + o_masks, mk.data(), mk.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(base + o_n, nk.data(), K * 4, hipMemcpyHostToDevice, ctx->stream));
+    if (nt) {
+        const ScanTile *dt = (const ScanTile *)(base + o_tiles);
+        const uint32_t *dm = (const uint32_t *)(base + o_masks), *dn = (const uint32_t *)(base + o_n);
+        uint64_t *dp = (uint64_t *)(base + o_parts);
+        switch (K) {
+            case 2: launch_multi<2>(ctx->stream, m, nt, dt, dm, dn, dp); break;
+            case 3: launch_multi<3>(ctx->stream, m, nt, dt, dm, dn, dp); break;
+            case 4: launch_multi<4>(ctx->stream, m, nt, dt, dm, dn, dp); break;
+            case 5: launch_multi<5>(ctx->stream, m, nt, dt, dm, dn, dp); break;
+            case 6: launch_multi<6>(ctx->stream, m, nt, dt, dm, dn, dp); break;
+            case 7: launch_multi<7>(ctx->stream, m, nt, dt, dm, dn, dp); break;
+            default: launch_multi<8>(ctx->stream, m, nt, dt, dm, dn, dp); break;
+        }
+        HIP_TRY(hipGetLastError());
+    }
+    const uint64_t items = n_windows * NP;
+    hipLaunchKernelGGL(scan_multi_finalize_kernel, dim3((uint32_t)((items + 127) / 128)), dim3(128), 0, ctx->stream,
+                       (const uint64_t *)(base + o_parts), (const WinDesc *)(base + o_wins), n_windows, K,
+                       (const uint32_t *)(base + o_n), (impop_pair_stats *)(base + o_out));
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(out_host, base + o_out, items * sizeof(impop_pair_stats), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return IMPOP_OK;
+}
+
+IMPOP_API int impop_afs(impop_ctx *ctx, const impop_matrix *m, const impop_window *windows, uint64_t n_windows,
+                        const uint64_t *mask, uint32_t *out_host) {
+    REQUIRE(ctx && m, "impop_afs: NULL argument");
+    if (!n_windows) return IMPOP_OK;
+    REQUIRE(windows && out_host, "impop_afs: NULL windows/out");
+    uint64_t longest = 0;
+    for (uint64_t i = 0; i < n_windows; ++i) {
+        REQUIRE(windows[i].site_begin <= windows[i].site_end && windows[i].site_end <= m->g.n_site,
+                "impop_afs: window %llu: bad site range", (unsigned long long)i);
+        longest = std::max(longest, windows[i].site_end - windows[i].site_begin);
+    }
+    REQUIRE(n_windows <= 65535, "impop_afs: at most 65535 windows per call");
+    std::vector<uint32_t> mk;
+    mask_to_dwords(mask, m->g.n_hap, m->g.wps, true, mk);
+    const uint32_t bins = popcount_vec(mk) + 1;
+    REQUIRE((size_t)bins * 4 <= 64 * 1024, "impop_afs: more than 16383 haplotypes in the mask");
+    HIP_TRY(hipSetDevice(ctx->device));
+    auto up = [](size_t x) { return (x + 255) / 256 * 256; };
+    const size_t o_mask = 0, o_wins = up((size_t)m->g.wps * 4), o_out = o_wins + up(n_windows * sizeof(impop_window)),
+                 total = o_out + n_windows * bins * 4;
+    void *d = nullptr;
+    int rc = ctx_scratch(ctx, total, &d);
+    if (rc) return rc;
+    char *base = (char *)d;
+    HIP_TRY(hipMemcpyAsync(base + o_mask, mk.data(), (size_t)m->g.wps * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(base + o_wins, windows, n_windows * sizeof(impop_window), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemsetAsync(base + o_out, 0, n_windows * bins * 4, ctx->stream));
+    const uint64_t chunks = (longest + 4095) / 4096;
+    if (chunks) {
+        REQUIRE(chunks < 0x7FFFFFFFull, "impop_afs: window too long");
+        hipLaunchKernelGGL(afs_kernel, dim3((uint32_t)chunks, (uint32_t)n_windows), dim3(256), (size_t)bins * 4, ctx->stream,
+                           m->d_sb, (const uint32_t *)(base + o_mask), m->g.wps, m->g.G, m->g.r,
+                           (const impop_window *)(base + o_wins), bins, (uint32_t *)(base + o_out));
+        HIP_TRY(hipGetLastError());
+    }
+    HIP_TRY(hipMemcpyAsync(out_host, base + o_out, n_windows * bins * 4, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     return IMPOP_OK;
 }

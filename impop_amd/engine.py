@@ -27,6 +27,8 @@ PAIRWISE_DTYPE = np.dtype([
     ("n_sites", "<u4"), ("reserved", "<u8")])
 assert PAIRWISE_DTYPE.itemsize == 96
 
+PAIR_DTYPE = np.dtype([("fst", "<f8"), ("pi_a", "<f8"), ("pi_b", "<f8"), ("pi_xy", "<f8"), ("dxy", "<f8"), ("da", "<f8")])
+
 WINDOW_DTYPE = np.dtype([("site_begin", "<u8"), ("site_end", "<u8"), ("seq_len", "<u8")])
 
 IDENTITY_KINDS = {"match": IDENTITY_MATCH, "dice": IDENTITY_DICE}
@@ -273,6 +275,28 @@ class BitMatrix:
             return p.fetch()
         finally:
             p.destroy()
+
+    def scan_multi(self, windows, pops) -> np.ndarray:
+        """All-pairs Hudson Fst of K disjoint populations in one pass -> array [n_windows, K(K-1)/2] of
+        (fst, pi_a, pi_b, pi_xy, dxy, da); pair order (0,1),(0,2),...,(1,2),..."""
+        w = make_windows(windows)
+        K = len(pops)
+        packed = np.concatenate([_mask_ptr(p, self.n_hap)[0] for p in pops]).astype(np.uint64)
+        out = np.zeros((len(w), K * (K - 1) // 2), dtype=PAIR_DTYPE)
+        check(self.ctx._lib.impop_scan_multi(self.ctx.handle, self.handle, w.ctypes.data_as(C.POINTER(Window)), len(w),
+                                             packed.ctypes.data_as(C.POINTER(C.c_uint64)), K,
+                                             out.ctypes.data_as(C.POINTER(_lib.PairStats))))
+        return out
+
+    def afs(self, windows, mask=None) -> np.ndarray:
+        """Allele-frequency spectrum per window: out[w, c] = #sites with c carriers among `mask`."""
+        w = make_windows(windows)
+        keep, ptr = _mask_ptr(mask, self.n_hap)
+        nP = self.n_hap if mask is None else int(np.unpackbits(keep.view(np.uint8), bitorder="little")[: self.n_hap].sum())
+        out = np.zeros((len(w), nP + 1), dtype=np.uint32)
+        check(self.ctx._lib.impop_afs(self.ctx.handle, self.handle, w.ctypes.data_as(C.POINTER(Window)), len(w), ptr,
+                                      out.ctypes.data_as(C.POINTER(C.c_uint32))))
+        return out
 
     def site_counts(self, site_begin: int, site_end: int, mask=None) -> np.ndarray:
         out = np.zeros(max(site_end - site_begin, 0), dtype=np.uint32)

@@ -165,6 +165,23 @@ int impop_scan(impop_ctx *ctx, const impop_matrix *m, const impop_window *window
                const uint64_t *mask_p, const uint64_t *mask_a, const uint64_t *mask_b,
                const impop_scan_params *params, impop_window_stats *out_host);
 
+/* K disjoint populations, all K(K-1)/2 Hudson Fst pairs in ONE streaming pass: replaces the
+ * panel loops of run_h_fst_panels.sh:60-71 (one run_h-fst.sh per population pair).
+ * masks: n_pop bitsets of ceil(n_hap/64) uint64 words each; populations must be disjoint.
+ * out: n_windows x K(K-1)/2 records, pairs ordered (0,1),(0,2),...,(1,2),...; per pair the six
+ * values of h-fst.py:233-249 with population k as A and l as B. */
+typedef struct impop_pair_stats {
+    double fst, pi_a, pi_b, pi_xy, dxy, da;
+} impop_pair_stats;
+int impop_scan_multi(impop_ctx *ctx, const impop_matrix *m, const impop_window *windows, uint64_t n_windows,
+                     const uint64_t *masks, uint32_t n_pop, impop_pair_stats *out_host);
+
+/* Allele-frequency spectrum per window (scripts/wip/op-afs.py): out[w*(nP+1) + c] = number of
+ * sites of window w at which exactly c haplotypes of `mask` (NULL = all; nP = its size) carry the
+ * allele. */
+int impop_afs(impop_ctx *ctx, const impop_matrix *m, const impop_window *windows, uint64_t n_windows,
+              const uint64_t *mask, uint32_t *out_host);
+
 /* Per-site allele counts c_s of the haplotypes in `mask` (NULL = all) for sites
  * [site_begin, site_end): the per-site allele frequency is c_s / n. */
 int impop_site_counts(impop_ctx *ctx, const impop_matrix *m, const uint64_t *mask, uint64_t site_begin,

@@ -379,3 +379,57 @@ def test_gram_determinism_and_batch(ctx):
         one = bm.pairwise_scan([w], None, None, None, kind="dice", threshold=0.9995, round_digits=None)[0]
         assert r.tobytes() == one.tobytes()
     bm.free()
+
+
+def test_scan_multi_equals_pairwise_hfst(ctx, oracle):
+    """K populations in one pass == K(K-1)/2 separate h-fst runs (the panel loop of
+    run_h_fst_panels.sh:60-71), each checked through the oracle's h-fst restatement."""
+    rng = np.random.default_rng(77)
+    n, W = 465, 4000
+    m = founder_matrix(rng, n, W, nf=8, pf=0.004, pp=0.0008)
+    bits = oracle.pack_hap_major(m)
+    bm = ctx.upload(bits, W)
+    sizes = [140, 88, 100, 60, 72]  # AFR / AMR / EAS / EUR / SAS haplotype counts (doc/where_hprc_data.md:4-10, x2)
+    perm = rng.permutation(n)
+    pops, o = [], 0
+    for s in sizes:
+        f = np.zeros(n, np.uint8); f[perm[o: o + s]] = 1; o += s
+        pops.append(f)
+    wins = [(0, W, W), (100, 1777, 50000), (2000, 2000, 5), (3999, 4000, 0)]
+    got = bm.scan_multi(wins, pops)
+    assert got.shape == (len(wins), 10)
+    ones = oracle.pack_mask(np.ones(n, np.uint8))
+    p = 0
+    for k in range(5):
+        for l in range(k + 1, 5):
+            for wi, (s0, s1, sl) in enumerate(wins):
+                want = oracle.window_allpairs(bits, n, s0, s1, ones, oracle.pack_mask(pops[k]), oracle.pack_mask(pops[l]), sl)
+                for key in ("fst", "pi_a", "pi_b", "pi_xy", "dxy", "da"):
+                    assert rel_close(float(got[wi, p][key]), want[key], REL, 1e-300), (k, l, wi, key)
+            # and identical to the 2-population scan of the same pair
+            two = bm.scan(wins, None, pops[k], pops[l])
+            for key in ("fst", "pi_a", "pi_b", "pi_xy", "dxy", "da"):
+                assert (got[:, p][key] == two[key]).all() or np.allclose(got[:, p][key], two[key], rtol=1e-15, atol=0, equal_nan=True)
+            p += 1
+    import impop_amd
+    with pytest.raises(impop_amd.ImpopError):
+        bm.scan_multi(wins, [pops[0], pops[0]])  # overlapping populations are rejected
+    bm.free()
+
+
+def test_afs_matches_numpy(ctx):
+    rng = np.random.default_rng(3)
+    n, W = 130, 9000
+    m = (rng.random((n, W)) < rng.beta(0.3, 2.0, size=W)[None, :]).astype(np.uint8)
+    bm = ctx.upload_dense(m)
+    sub = (rng.random(n) < 0.6).astype(np.uint8)
+    wins = [(0, W), (17, 5000), (4096, 8192), (8999, 9000), (10, 10)]
+    for mask, rows in ((None, np.ones(n, bool)), (sub, sub.astype(bool))):
+        got = bm.afs(wins, mask)
+        nP = int(rows.sum())
+        assert got.shape == (len(wins), nP + 1)
+        for (s0, s1), g in zip(wins, got):
+            c = m[rows, s0:s1].sum(0)
+            assert (g == np.bincount(c, minlength=nP + 1)).all()
+            assert int(g.sum()) == s1 - s0
+    bm.free()

@@ -55,6 +55,8 @@ def main():
     ap.add_argument("--bed", "-b", required=True)
     ap.add_argument("--format", choices=["pica2", "hfst", "tajd", "all"], default="all")
     ap.add_argument("-A", "--pop-a"); ap.add_argument("-B", "--pop-b")
+    ap.add_argument("--panel", nargs="+", metavar="POP.txt", help="hfst: K >= 2 disjoint population lists; every pair "
+                    "in ONE pass (replaces run_h_fst_panels.sh); one table per pair, labelled POP_A-vs-POP_B")
     ap.add_argument("-l", "--sample-list", help="tajd: sample list (run_tajd.sh -l); n = its line count")
     ap.add_argument("-u", "--subset", help="pica2: --subset-sequence-list")
     ap.add_argument("-t", "--threshold", type=float, default=None)
@@ -92,6 +94,24 @@ def main():
         if not mask_a.any() or not mask_b.any():
             print("Error: No valid sequences found in one or both populations", file=sys.stderr)  # h-fst.py:319-321
             sys.exit(1)
+    if args.panel:
+        labels = [os.path.splitext(os.path.basename(f))[0] for f in args.panel]
+        pops = [flags_for(f, names)[0] for f in args.panel]
+        pr = bm.scan_multi(wins, pops)
+        p = 0
+        for k in range(len(pops)):
+            for l in range(k + 1, len(pops)):
+                print(f"# {labels[k]}-vs-{labels[l]}", file=out)
+                print("REGION\tLENGTH\tFST\tPI_A\tPI_B\tPI_XY\tDXY\tDA", file=out)
+                for reg, (b, e, L), r in zip(regions, wins, pr[:, p]):
+                    print(f"{reg}\t{L}\t{float(r['fst']):.8f}\t{float(r['pi_a']):.8f}\t{float(r['pi_b']):.8f}\t"
+                          f"{float(r['pi_xy']):.8f}\t{float(r['dxy']):.8f}\t{float(r['da']):.8f}", file=out)
+                p += 1
+        if args.output:
+            out.close()
+        bm.free()
+        ctx.close()
+        return
     if need_pairwise:
         thr = 0.99 if args.threshold is None else args.threshold  # pica2.py:175 CLI default
         res = bm.pairwise_scan(wins, mask_p, mask_a, mask_b, kind=args.identity, threshold=thr, round_digits=args.round_digits)

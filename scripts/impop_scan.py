@@ -64,8 +64,26 @@ def main():
     ap.add_argument("-p", "--region-prefix", default="CHM13#0#")
     ap.add_argument("-o", "--output")
     ap.add_argument("--identity", choices=["match", "dice"], default="match")
-    ap.add_argument("--device", type=int, default=0)
+    ap.add_argument("--device", type=int, default=None, help="default: LOCAL_RANK, else 0")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend when launched with WORLD_SIZE > 1 "
+                    "(nccl = RCCL over xGMI; gloo for rehearsals)")
     args = ap.parse_args()
+    # Multi-GPU: `python -m torch.distributed.run --nproc-per-node N scripts/impop_scan.py ...` — the BED rows
+    # are sharded over ranks, each rank uploads only the slab its windows touch, scans it, and ONE
+    # all-gather of the fixed-size records brings everything to rank 0, which prints.
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if args.backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
+    if args.device is None:
+        args.device = local_rank if (world == 1 or args.backend == "nccl") else 0
 
     mf = load_matrix(args.matrix)
     names = mf.names
@@ -76,11 +94,24 @@ def main():
         wins.append((b, en, e - s))  # seq_len = LENGTH = end - start (run_pica2_impg.sh:133)
         region = f"{chrom}:{s}-{e}" if chrom.startswith(args.region_prefix) else f"{args.region_prefix}{chrom}:{s}-{e}"
         regions.append(region)
-    out = open(args.output, "w") if args.output else sys.stdout
+    out = (open(args.output, "w") if args.output else sys.stdout) if rank == 0 else open(os.devnull, "w")
     ctx = impop_amd.Context(args.device)
     need_pairwise = args.format == "pica2" and ((args.threshold is not None and args.threshold < 1.0) or args.round_digits is not None
                                                  or args.identity != "match")
-    bm = ctx.upload(mf.bits, mf.n_site, keep_hap_major=need_pairwise)
+    all_wins = impop_amd.make_windows(wins)
+    if world > 1:
+        from impop_amd.distributed import shard_windows
+        loc, s0, s1, _ = shard_windows(all_wins, world, rank)
+        w0, w1 = s0 // 64, (s1 + 63) // 64  # slab = whole 64-bit words of the hap-major rows
+        slab = np.ascontiguousarray(mf.bits[:, w0:w1]) if len(loc) else np.zeros((mf.n_hap, 1), np.uint64)
+        shift = s0 - 64 * w0
+        loc = loc.copy()
+        loc["site_begin"] += np.uint64(shift)
+        loc["site_end"] += np.uint64(shift)
+        bm = ctx.upload(slab, max(min(mf.n_site, 64 * w1) - 64 * w0, 0), keep_hap_major=need_pairwise)
+        wins = [(int(w["site_begin"]), int(w["site_end"]), int(w["seq_len"])) for w in loc]
+    else:
+        bm = ctx.upload(mf.bits, mf.n_site, keep_hap_major=need_pairwise)
     mask_p = mask_a = mask_b = None
     sample_count = mf.n_hap
     if args.sample_list:
@@ -117,6 +148,12 @@ def main():
         res = bm.pairwise_scan(wins, mask_p, mask_a, mask_b, kind=args.identity, threshold=thr, round_digits=args.round_digits)
     else:
         res = bm.scan(wins, mask_p, mask_a, mask_b)
+    if world > 1:
+        from impop_amd.distributed import gather_records
+        import torch
+        dev = torch.device("cuda", local_rank) if args.backend == "nccl" else None
+        res = gather_records(res, len(all_wins), world, rank, dev)
+    wins = [(int(w["site_begin"]), int(w["site_end"]), int(w["seq_len"])) for w in all_wins]
     fmt = args.format
     thr_txt = "1.0" if args.threshold is None and not need_pairwise else str(args.threshold if args.threshold is not None else 0.99)
     r_txt = "" if args.round_digits is None else str(args.round_digits)
@@ -142,10 +179,14 @@ def main():
             D = float(r["tajima_d"])
             taj = "NA" if D != D else repr(D)  # run_tajd.sh:192-194
             print(f"{reg}\t{L}\t{sample_count}\t{int(r['s_all'])}\t{float(r['pi_site']):.8f}\t{taj}", file=out)
-    if args.output:
+    if args.output or rank != 0:
         out.close()
     bm.free()
     ctx.close()
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

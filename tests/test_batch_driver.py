@@ -65,3 +65,31 @@ def test_batch_driver_tables(tmp_path, oracle):
         sim = oracle.identity(oracle.pairwise_counts(bits, n, s0, s1), s1 - s0, 0)
         pi, ps, _, _ = oracle.pica2(sim, 0.995, L, 4)
         assert l2[1 + k] == f"{reg}\t{L}\t0.995\t4\t{ps:.8f} (sequence length: {L})"
+
+
+def test_batch_driver_two_ranks_equal_one(tmp_path):
+    """The driver sharded over 2 ranks (gloo rehearsal: both ranks share the one GPU of the test
+    box; on a node it is one rank per GPU over RCCL) prints exactly what 1 rank prints."""
+    import socket
+
+    from impop_amd import matrixio
+    rng = np.random.default_rng(21)
+    n, W = 40, 64 * 257 + 5
+    m = (rng.random((n, W)) < 0.3).astype(np.uint8)
+    names = [f"S{i // 2:03d}#{i % 2 + 1}#chr9:0-{W}" for i in range(n)]
+    matrixio.save_matrix(str(tmp_path / "m.npz"), matrixio.from_dense(m, names, origin=0, contig="CHM13#0#chr9"))
+    with open(tmp_path / "w.bed", "w") as f:
+        for s in range(0, W - 1000, 700):  # overlapping windows, unaligned
+            f.write(f"chr9\t{s}\t{min(s + 1000, W)}\n")
+    (tmp_path / "A.txt").write_text("\n".join(f"S{i:03d}" for i in range(0, 6)) + "\n")
+    (tmp_path / "B.txt").write_text("\n".join(f"S{i:03d}" for i in range(8, 15)) + "\n")
+    base = [os.path.join(ROOT, "scripts", "impop_scan.py"), "--matrix", str(tmp_path / "m.npz"), "--bed", str(tmp_path / "w.bed"),
+            "--format", "all", "-A", str(tmp_path / "A.txt"), "-B", str(tmp_path / "B.txt")]
+    one = subprocess.run([sys.executable] + base, capture_output=True, text=True)
+    assert one.returncode == 0, one.stderr
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", str(port)] + base + ["--backend", "gloo", "-o", str(tmp_path / "two.tsv")],
+                         capture_output=True, text=True)
+    assert two.returncode == 0, two.stderr[-2000:]
+    assert open(tmp_path / "two.tsv").read() == one.stdout

@@ -173,19 +173,37 @@ def main():
     in_a = np.zeros(n, np.uint8); in_a[: min(140, n)] = 1
     in_b = np.zeros(n, np.uint8); in_b[min(140, n): min(240, n)] = 1
     plan = bm.plan(windows, None, in_a, in_b, tile_blocks=args.tile_blocks)
-    local = torch.empty(NW * 128, dtype=torch.uint8, device=dev)
+    # double-buffered records: the all-gather of step i (RCCL stream) overlaps the scan of step i+1
+    # (compute stream); a buffer is rewritten only after its previous gather has been waited for
+    bufs = [torch.empty(NW * 128, dtype=torch.uint8, device=dev) for _ in range(2)]
     gdev = dev if backend == "nccl" else torch.device("cpu")
-    gathered = torch.empty(world * NW * 128, dtype=torch.uint8, device=gdev) if world > 1 else None
+    gathered = [torch.empty(world * NW * 128, dtype=torch.uint8, device=gdev) for _ in range(2)] if world > 1 else None
+    works = [None, None]
+    counter = [0]
 
     def step():
-        plan.launch(local.data_ptr())
+        b = counter[0] & 1
+        counter[0] += 1
+        if works[b] is not None:
+            works[b].wait()
+        plan.launch(bufs[b].data_ptr())
         if world > 1:
-            dist.all_gather_into_tensor(gathered, local if backend == "nccl" else local.cpu())
+            works[b] = dist.all_gather_into_tensor(gathered[b], bufs[b] if backend == "nccl" else bufs[b].cpu(), async_op=True)
+
+    def drain():
+        for b in (0, 1):
+            if works[b] is not None:
+                works[b].wait()
+                works[b] = None
+        torch.cuda.synchronize(dev)
 
     # ---- parity gate before timing (rank 0): GPU records vs the CPU oracle on sampled windows
     step()
-    torch.cuda.synchronize(dev)
-    recs = np.frombuffer(local.cpu().numpy().tobytes(), dtype=impop_amd.STATS_DTYPE)
+    drain()
+    recs = np.frombuffer(bufs[0].cpu().numpy().tobytes(), dtype=impop_amd.STATS_DTYPE)
+    if world > 1:  # every rank must hold every rank's records after the gather
+        allrec = np.frombuffer(gathered[0].cpu().numpy().tobytes(), dtype=impop_amd.STATS_DTYPE)
+        assert allrec[rank * NW: (rank + 1) * NW].tobytes() == recs.tobytes()
     cpu, first = None, None
     if rank == 0:
         from oracle import oracle as orc
@@ -206,6 +224,7 @@ def main():
     # ---- timed region
     for _ in range(args.warmup):
         step()
+    drain()
     plan.timing(True)
     if world > 1:
         dist.barrier()
@@ -213,7 +232,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-    torch.cuda.synchronize(dev)
+    drain()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize(dev)

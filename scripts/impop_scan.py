@@ -125,6 +125,9 @@ def main():
         if not mask_a.any() or not mask_b.any():
             print("Error: No valid sequences found in one or both populations", file=sys.stderr)  # h-fst.py:319-321
             sys.exit(1)
+    if args.panel and world > 1:
+        print("Error: --panel is not sharded yet; run it on one GPU", file=sys.stderr)
+        sys.exit(2)
     if args.panel:
         labels = [os.path.splitext(os.path.basename(f))[0] for f in args.panel]
         pops = [flags_for(f, names)[0] for f in args.panel]

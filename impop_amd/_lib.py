@@ -11,7 +11,7 @@ import importlib.util
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_HERE, "libimpop_hip.so")
+SO_PATH = os.environ.get("IMPOP_HIP_LIBRARY") or os.path.join(_HERE, "libimpop_hip.so")  # env override: tuning builds
 
 
 class ImpopError(RuntimeError):

@@ -69,12 +69,12 @@ struct impop_matrix {
     uint32_t *d_sb = nullptr;   // SB64 layout, n_block*64*wps dwords
     uint64_t sb_bytes = 0;
     // RB32 — row-group-blocked hap-major copy, operand layout of the Gram kernel (optional,
-    // IMPOP_KEEP_HAP_MAJOR): rows are grouped by 32, sites by 128-site quads (4 dwords), and one
-    // (group, quad) cell holds the 32 rows' uint4 contiguously (512 B = one coalesced wave load):
-    //     dword(row, d) @ (((row>>5) * rb_nq + (d>>2)) * 32 + (row&31)) * 4 + (d&3)
+    // IMPOP_KEEP_HAP_MAJOR): rows are grouped by 32, sites by 64-site cells (2 dwords), and one
+    // (group, cell) holds the 32 rows' dword pairs contiguously (256 B = one coalesced wave load):
+    //     dword(row, d) @ (((row>>5) * rb_nb + (d>>1)) * 32 + (row&31)) * 2 + (d&1)
     uint32_t *d_rb = nullptr;
-    uint64_t rb_nq = 0;         // quads per row incl. one quad of slack (prefetch)
-    uint32_t n_hap_pad = 0;     // rows padded to a multiple of 128 (zero rows)
+    uint64_t rb_nb = 0;         // cells per row group incl. 4 cells of slack (prefetch)
+    uint32_t n_hap_pad = 0;     // rows padded to a multiple of 96 (zero rows; Gram tiles are 96 wide)
     uint64_t rb_bytes = 0;
     int device = 0;
 };
@@ -85,8 +85,8 @@ int ensure_tajima_consts(impop_ctx *ctx, int64_t n);  // fills ctx->d_taj for n 
 
 // layout.hip
 int launch_hm_to_sb(impop_ctx *ctx, const uint32_t *d_hm, uint64_t hm_stride, const SbGeom &g, uint32_t *d_sb);
-// rb_nq == 0: plain hap-major rows of hm_stride dwords; else RB32 addressing with rb_nq quads per row
+// rb_nb == 0: plain hap-major rows of hm_stride dwords; else RB32 addressing with rb_nb cells per row group
 int launch_sb_to_hm(impop_ctx *ctx, const uint32_t *d_sb, const SbGeom &g, uint64_t blk_begin, uint64_t blk_end,
-                    uint32_t *d_hm, uint64_t hm_stride, uint32_t n_rows, uint64_t rb_nq = 0);
+                    uint32_t *d_hm, uint64_t hm_stride, uint32_t n_rows, uint64_t rb_nb = 0);
 
 }  // namespace impop

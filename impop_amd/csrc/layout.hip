@@ -63,7 +63,7 @@ __global__ __launch_bounds__(256) void hm_to_sb_kernel(const uint32_t *__restric
 __global__ __launch_bounds__(256) void sb_to_hm_kernel(const uint32_t *__restrict__ sb, uint32_t wps, uint32_t G,
                                                        uint32_t r, uint64_t blk_begin, uint64_t blk_end,
                                                        uint32_t *__restrict__ hm, uint64_t hm_stride,
-                                                       uint32_t n_rows, uint64_t rb_nq) {
+                                                       uint32_t n_rows, uint64_t rb_nb) {
     const uint32_t lane = threadIdx.x & 63;
     const uint64_t b = blk_begin + (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (b >= blk_end) return;  // wave-uniform
@@ -78,7 +78,7 @@ __global__ __launch_bounds__(256) void sb_to_hm_kernel(const uint32_t *__restric
         const uint32_t row = 32 * k + lane;
         if (lane < 32 && row < n_rows) {
             const uint64_t d = 2 * (b - blk_begin);  // first of the two dwords of this 64-site block
-            uint32_t *p = rb_nq ? hm + ((((uint64_t)(row >> 5) * rb_nq + (d >> 2)) * 32 + (row & 31)) * 4 + (d & 3))
+            uint32_t *p = rb_nb ? hm + ((((uint64_t)(row >> 5) * rb_nb + (d >> 1)) * 32 + (row & 31)) * 2)
                                 : hm + (uint64_t)row * hm_stride + d;
             p[0] = (uint32_t)keep;
             p[1] = (uint32_t)(keep >> 32);
@@ -104,7 +104,7 @@ int launch_hm_to_sb(impop_ctx *ctx, const uint32_t *d_hm, uint64_t hm_stride, co
     if (g.n_block == 0) return IMPOP_OK;
     const uint64_t grid = (g.n_block + 3) / 4;
     REQUIRE(grid < 0x7FFFFFFFull, "matrix too long for one launch (%llu blocks)", (unsigned long long)g.n_block);
-    const uint32_t n_rows = (g.n_hap + 127) / 128 * 128;
+    const uint32_t n_rows = (g.n_hap + 95) / 96 * 96;
     hipLaunchKernelGGL(hm_to_sb_kernel, dim3((uint32_t)grid), dim3(256), 0, ctx->stream, d_hm, hm_stride, n_rows, g.wps,
                        g.G, g.r, g.n_block, d_sb);
     HIP_TRY(hipGetLastError());
@@ -112,12 +112,12 @@ int launch_hm_to_sb(impop_ctx *ctx, const uint32_t *d_hm, uint64_t hm_stride, co
 }
 
 int launch_sb_to_hm(impop_ctx *ctx, const uint32_t *d_sb, const SbGeom &g, uint64_t blk_begin, uint64_t blk_end,
-                    uint32_t *d_hm, uint64_t hm_stride, uint32_t n_rows, uint64_t rb_nq) {
+                    uint32_t *d_hm, uint64_t hm_stride, uint32_t n_rows, uint64_t rb_nb) {
     if (blk_end <= blk_begin) return IMPOP_OK;
     const uint64_t grid = (blk_end - blk_begin + 3) / 4;
     REQUIRE(grid < 0x7FFFFFFFull, "range too long for one launch");
     hipLaunchKernelGGL(sb_to_hm_kernel, dim3((uint32_t)grid), dim3(256), 0, ctx->stream, d_sb, g.wps, g.G, g.r, blk_begin,
-                       blk_end, d_hm, hm_stride, n_rows, rb_nq);
+                       blk_end, d_hm, hm_stride, n_rows, rb_nb);
     HIP_TRY(hipGetLastError());
     return IMPOP_OK;
 }
@@ -163,7 +163,7 @@ static int alloc_matrix(impop_ctx *ctx, uint32_t n_hap, uint64_t n_site, bool wa
     impop_matrix *m = new impop_matrix();
     m->g = make_geom(n_hap, n_site);
     m->device = ctx->device;
-    m->n_hap_pad = (n_hap + 127) / 128 * 128;  // Gram tiles are 128 haplotypes wide
+    m->n_hap_pad = (n_hap + 95) / 96 * 96;  // Gram tiles are 96 haplotypes wide (3 row groups of 32)
     m->sb_bytes = m->g.n_block * 64ull * m->g.wps * 4ull;
     // one extra block of slack so software-pipelined kernels may prefetch one block past the end
     hipError_t e = hipMalloc((void **)&m->d_sb, m->sb_bytes + 64ull * m->g.wps * 4ull + 256);
@@ -178,8 +178,8 @@ static int alloc_matrix(impop_ctx *ctx, uint32_t n_hap, uint64_t n_site, bool wa
         return hip_fail(e, "hipMemsetAsync", __FILE__, __LINE__);
     }
     if (want_hm) {
-        m->rb_nq = (m->g.n_block * 2 + 3) / 4 + 1;  // quads per row + one quad of prefetch slack
-        m->rb_bytes = (uint64_t)(m->n_hap_pad / 32) * m->rb_nq * 32ull * 16ull;
+        m->rb_nb = m->g.n_block + 4;  // 64-site cells per row group + prefetch slack
+        m->rb_bytes = (uint64_t)(m->n_hap_pad / 32) * m->rb_nb * 32ull * 8ull;
         e = hipMalloc((void **)&m->d_rb, m->rb_bytes);
         if (e != hipSuccess) {
             hipFree(m->d_sb);
@@ -241,7 +241,7 @@ IMPOP_API int impop_matrix_upload(impop_ctx *ctx, const uint64_t *bits, uint32_t
     rc = launch_hm_to_sb(ctx, d_hm, hm_stride, m->g, m->d_sb);
     if (rc) return fail(rc);
     if (want_rb) {
-        rc = launch_sb_to_hm(ctx, m->d_sb, m->g, 0, m->g.n_block, m->d_rb, 0, m->n_hap_pad, m->rb_nq);
+        rc = launch_sb_to_hm(ctx, m->d_sb, m->g, 0, m->g.n_block, m->d_rb, 0, m->n_hap_pad, m->rb_nb);
         if (rc) return fail(rc);
     }
     e = hipStreamSynchronize(ctx->stream);  // the caller may free `bits` on return
@@ -295,7 +295,7 @@ IMPOP_API int impop_matrix_synthetic(impop_ctx *ctx, uint32_t n_hap, uint64_t n_
                            wps, m->g.G, m->g.r, m->g.n_block, n_site, m->d_sb);
         if ((e = hipGetLastError()) != hipSuccess) return fail(hip_fail(e, "synth_sb_kernel", __FILE__, __LINE__));
         if (want_hm) {
-            rc = launch_sb_to_hm(ctx, m->d_sb, m->g, 0, m->g.n_block, m->d_rb, 0, m->n_hap_pad, m->rb_nq);
+            rc = launch_sb_to_hm(ctx, m->d_sb, m->g, 0, m->g.n_block, m->d_rb, 0, m->n_hap_pad, m->rb_nb);
             if (rc) return fail(rc);
         }
     }

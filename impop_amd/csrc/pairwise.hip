@@ -21,21 +21,22 @@ namespace impop {
 //     dominate (LDS write path ~79 B/clk/CU); 9 us/window.
 //   * int8 MFMA, register-only, rows 1.6 MB apart (plain hap-major): every wave-load touched 32
 //     cache lines for 512 useful bytes and the address path, not the ALUs, set the pace; 9-11 us.
-//   * this kernel: the operand is stored ROW-GROUP-BLOCKED (RB32, internal.h) so one wave-load of
-//     a 128-site quad for 32 rows is 512 contiguous bytes.
-// One WAVE owns one 64 x 128 half of a 128 x 128 tile: 2 x 4 MFMA tiles of 32 x 32 = 128
-// accumulator registers, leaving room for TWO waves per SIMD (a lone wave issues one VALU
-// instruction per ~8 cycles, two or more reach one per 2.6 / 4.8 cycles).  Lane l supplies row
+//   * 64 x 128 per wave on a ROW-GROUP-BLOCKED operand (RB32, internal.h: one wave-load of a cell
+//     for 32 rows is contiguous): 6.4 us/window, MfmaUtil 59 %, VALU ~85 % busy (PMC).
+//   * this kernel: 96 x 96 per wave, diagonal tiles reuse A as B, no register copies.
+// One WAVE owns one 96 x 96 tile (3 x 3 MFMA tiles of 32 x 32 = 144 accumulator registers), which
+// still leaves room for TWO waves per SIMD (a lone wave issues one VALU instruction per ~8
+// cycles, two or more reach one per 2.6 / 4.8 cycles).  Lane l supplies row
 // (l & 31) of each 32-row group and the 16 sites [16 (l>>5), +16) of a 32-site k-step.  Expansion:
 // y = x & 0x0F0F and z = (x >> 4) & 0x0F0F hold the four nibbles as clean bytes, v_mul_u32_u24
 // with an SDWA byte select spreads one nibble per instruction (nibble * 0x204081: copies at bits
 // 0-3, 7-10, 14-17, 21-24, no carries) and one AND keeps bits 0, 8, 16, 24: 12 VALU ops per
-// fragment, 6 fragments per 8 MFMAs.  MFMA and VALU runs of one wave do not overlap unless finely
+// fragment; 6 fragments per 9 MFMAs (off-diagonal), 3 per 6 (diagonal).  MFMA and VALU runs of one wave do not overlap unless finely
 // interleaved (tools/micro/mfma_rate.hip: 257 + 368 -> 589 cycles), hence the software pipeline
 // (expand step t+1 under the MFMAs of step t) and the sched_group_barrier issue pattern.
 // Both MFMA operands use the same (lane>>5, byte) -> site mapping, so the result does not depend
 // on the instruction's internal k order; C/D map: col = lane&31, row = (reg&3)+8(reg>>2)+4(lane>>5).
-constexpr int GT = 128;  // tile edge (haplotypes)
+constexpr int GT = 96;  // tile edge (haplotypes): 3 row groups of 32
 
 struct GramWindow {
     uint64_t site_begin, site_end;
@@ -68,13 +69,111 @@ __device__ __forceinline__ i32x4 expand16(uint32_t xs /* the lane's 16 bits in t
     return r;
 }
 
-// grid: 1-D, tasks = (window, tile pair, row half).  Consecutive block ids are dealt round-robin
+// One task = one 96 x 96 tile pair (ti <= tj) of one window (x one K-slice).  3 x 3 MFMA tiles of
+// 32 x 32 per wave (144 accumulators, two waves per SIMD).  Off-diagonal tiles: 6 fragment
+// expansions feed 9 MFMAs per 32-site step; diagonal tiles: B == A, so 3 expansions feed the 6
+// MFMAs on and above the block diagonal.  Measured motivation (rocprofv3 PMC on the 64 x 128
+// predecessor): MfmaUtil 59 %, VALU ~85 % busy, every issue pattern within 1 % => fewer
+// expansions per MFMA is the lever (96 also pads 465 haplotypes to 480 instead of 512).
+// Pipeline (no register copies): the two 64-site cells PA / PB alternate, fragments F / G alternate;
+// a cell is reloaded right after its last use, three steps before its next use.
+template <bool DIAG>
+__device__ __forceinline__ void gram_task(const uint32_t *__restrict__ rb, uint64_t nb_row, uint32_t ti, uint32_t tj,
+                                          const GramWindow w, uint32_t ks, uint32_t ksplit, int32_t *__restrict__ o,
+                                          uint32_t ld) {
+    constexpr int NB = DIAG ? 0 : 3;  // B row groups to load (diagonal: reuse A)
+    const uint32_t lane = threadIdx.x & 63, r32 = lane & 31, sh = 16 * (lane >> 5);
+    const uint32_t kmul = 0x204081u;
+    i32x16 acc[3][3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[a][b][e] = 0;
+    if (w.site_end > w.site_begin) {
+        // 32-bit, window-relative indices: cell c = 64 sites = dwords 2c, 2c+1 (relative to the cell of site_begin)
+        const uint64_t cell0 = w.site_begin >> 6;
+        const uint32_t ncell = (uint32_t)(((w.site_end + 63) >> 6) - cell0);
+        const uint32_t cbeg = (uint32_t)((uint64_t)ncell * ks / ksplit);
+        const uint32_t cend = (uint32_t)((uint64_t)ncell * (ks + 1) / ksplit);  // this K-slice: cells [cbeg, cend)
+        const uint32_t f = (uint32_t)((w.site_begin >> 5) - 2 * cell0);         // first window dword (0 or 1)
+        const uint32_t l = (uint32_t)(((w.site_end + 31) >> 5) - 1 - 2 * cell0);  // last window dword
+        const uint32_t first_mask = 0xFFFFFFFFu << (w.site_begin & 31);
+        const uint32_t last_mask = (w.site_end & 31) ? (0xFFFFFFFFu >> (32 - (w.site_end & 31))) : 0xFFFFFFFFu;
+        auto mask_of = [&](uint32_t d) -> uint32_t {  // wave-uniform; zero outside the window AND outside this slice
+            uint32_t m = (d >= f && d <= l && d >= 2 * cbeg && d < 2 * cend) ? 0xFFFFFFFFu : 0u;
+            if (d == f) m &= first_mask;
+            if (d == l) m &= last_mask;
+            return m;
+        };
+        // RB32: dword (row, d) @ (((row>>5) * nb_row + (d>>1)) * 32 + (row&31)) * 2 + (d&1)
+        const uint32_t *gA = rb + (((uint64_t)(ti * 3) * nb_row + cell0) * 32 + r32) * 2;
+        const uint32_t *gB = rb + (((uint64_t)(tj * 3) * nb_row + cell0) * 32 + r32) * 2;
+        const uint64_t g32 = nb_row * 64;  // dwords between consecutive 32-row groups
+        typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+        u32x2 PA_a[3], PB_a[3], PA_b[3], PB_b[3];
+        auto load_cell = [&](u32x2 (&ca)[3], u32x2 (&cb)[3], uint32_t c) {  // slack cells keep this in bounds
+#pragma unroll
+            for (int g = 0; g < 3; ++g) ca[g] = *reinterpret_cast<const u32x2 *>(gA + g * g32 + (uint64_t)c * 64);
+#pragma unroll
+            for (int g = 0; g < NB; ++g) cb[g] = *reinterpret_cast<const u32x2 *>(gB + g * g32 + (uint64_t)c * 64);
+        };
+        i32x4 Fa[3], Fb[3], Ga[3], Gb[3];
+        auto expand_step = [&](i32x4 (&fa)[3], i32x4 (&fb)[3], const u32x2 (&ca)[3], const u32x2 (&cb)[3], int half, uint32_t d) {
+            const uint32_t m = mask_of(d);  // masking A suffices: a zero byte kills the product
+#pragma unroll
+            for (int g = 0; g < 3; ++g) fa[g] = expand16(((half ? ca[g].y : ca[g].x) & m) >> sh, kmul);
+#pragma unroll
+            for (int g = 0; g < NB; ++g) fb[g] = expand16((half ? cb[g].y : cb[g].x) >> sh, kmul);
+        };
+        auto mfma_step = [&](const i32x4 (&fa)[3], const i32x4 (&fb)[3]) {
+#pragma unroll
+            for (int a = 0; a < 3; ++a)
+#pragma unroll
+                for (int b = 0; b < 3; ++b) {
+                    if (DIAG && b < a) continue;  // strictly below the block diagonal: by symmetry
+                    acc[a][b] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[a], DIAG ? fa[b] : fb[b], acc[a][b], 0, 0, 0);
+                }
+        };
+        load_cell(PA_a, PA_b, cbeg);
+        load_cell(PB_a, PB_b, cbeg + 1);
+        expand_step(Fa, Fb, PA_a, PA_b, 0, 2 * cbeg);
+        for (uint32_t c = cbeg; c < cend; c += 2) {
+            expand_step(Ga, Gb, PA_a, PA_b, 1, 2 * c + 1);   // cell c, second dword: last use of PA
+            load_cell(PA_a, PA_b, c + 2);
+            mfma_step(Fa, Fb);
+            expand_step(Fa, Fb, PB_a, PB_b, 0, 2 * c + 2);   // cell c+1 (zero mask if past the slice)
+            mfma_step(Ga, Gb);
+            expand_step(Ga, Gb, PB_a, PB_b, 1, 2 * c + 3);   // last use of PB
+            load_cell(PB_a, PB_b, c + 3);
+            mfma_step(Fa, Fb);
+            expand_step(Fa, Fb, PA_a, PA_b, 0, 2 * c + 4);   // cell c+2 for the next iteration
+            mfma_step(Ga, Gb);
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+            if (DIAG && b < a) continue;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const uint32_t row = ti * GT + 32 * a + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+                const uint32_t col = tj * GT + 32 * b + r32;
+                if (ksplit == 1) o[(uint64_t)row * ld + col] = acc[a][b][e];
+                else atomicAdd(&o[(uint64_t)row * ld + col], acc[a][b][e]);
+            }
+        }
+}
+
+// grid: 1-D, tasks = (window, tile pair) x K-slice.  Consecutive block ids are dealt round-robin
 // over the 8 XCDs, so id % 8 selects the window inside a group of 8 windows: all tasks of one
 // window then share one XCD's L2 (speed only; any placement is correct).
 // ksplit > 1: the site range of a window is cut into ksplit slices handled by different waves that
 // atomicAdd into a zero-initialised output (integer adds commute: still bit-reproducible); used
 // when there are too few (window, tile) tasks to put two waves on every SIMD.
-__global__ __launch_bounds__(64, 2) void gram_mfma_kernel(const uint32_t *__restrict__ rb, uint64_t nq_row,
+__global__ __launch_bounds__(64, 2) void gram_mfma_kernel(const uint32_t *__restrict__ rb, uint64_t nb_row,
                                                           uint32_t n_tiles, uint32_t tasks_per_win, uint32_t n_win,
                                                           uint32_t ksplit, const GramWindow *__restrict__ wins,
                                                           int32_t *__restrict__ out, uint32_t ld, uint64_t out_stride) {
@@ -90,108 +189,12 @@ __global__ __launch_bounds__(64, 2) void gram_mfma_kernel(const uint32_t *__rest
         win = id / tasks_per_win;
         task = id % tasks_per_win;
     }
-    uint32_t rem = task >> 1, ti = 0;
-    const uint32_t half = task & 1;
+    uint32_t rem = task, ti = 0;
     while (rem >= n_tiles - ti) { rem -= n_tiles - ti; ++ti; }
     const uint32_t tj = ti + rem;
-    const GramWindow w = wins[win];
-    const uint32_t lane = threadIdx.x & 63, r32 = lane & 31, sh = 16 * (lane >> 5);
-    const uint32_t row0 = ti * GT + 64 * half;
-    const uint32_t kmul = 0x204081u;
-    i32x16 acc[2][4];
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < 4; ++b)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[a][b][e] = 0;
-    if (w.site_end > w.site_begin) {
-        const uint64_t d0 = w.site_begin >> 5, d1 = (w.site_end + 31) >> 5;
-        const uint64_t c0 = d0 & ~3ull;
-        // everything inside the loop is 32-bit and relative to c0 (gfx9 has no 64-bit scalar
-        // less-than: 64-bit loop/mask compares would run on the VALU and split the body into blocks)
-        const uint32_t f = (uint32_t)(d0 - c0);        // first window dword, 0..3
-        const uint32_t l = (uint32_t)(d1 - 1 - c0);    // last window dword
-        const uint32_t nq_all = (l >> 2) + 1;          // quads of the window
-        const uint32_t qbeg = (uint32_t)((uint64_t)nq_all * ks / ksplit);
-        const uint32_t nq = (uint32_t)((uint64_t)nq_all * (ks + 1) / ksplit);  // this slice: quads [qbeg, nq)
-        const uint32_t first_mask = 0xFFFFFFFFu << (w.site_begin & 31);
-        const uint32_t last_mask = (w.site_end & 31) ? (0xFFFFFFFFu >> (32 - (w.site_end & 31))) : 0xFFFFFFFFu;
-        // RB32: dword (row, d) @ (((row>>5) * nq_row + (d>>2)) * 32 + (row&31)) * 4 + (d&3)
-        const uint32_t *gA = rb + (((uint64_t)(row0 >> 5) * nq_row + (c0 >> 2)) * 32 + r32) * 4;
-        const uint32_t *gB = rb + (((uint64_t)((tj * GT) >> 5) * nq_row + (c0 >> 2)) * 32 + r32) * 4;
-        const uint64_t g32 = nq_row * 128;  // dwords between consecutive 32-row groups
-        auto mask_of = [&](uint32_t d) -> uint32_t {  // wave-uniform, d relative to c0
-            uint32_t m = (d >= f && d <= l) ? 0xFFFFFFFFu : 0u;
-            if (d == f) m &= first_mask;
-            if (d == l) m &= last_mask;
-            return m;
-        };
-        u32x4 qa[2], qb[4], na[2], nb[4];
-        // the allocation carries one quad of slack per row group, so the one-quad-ahead prefetch
-        // is always in bounds (whatever it reads past the window is masked to zero on the A side)
-        auto fetch = [&](uint32_t qi) {
-#pragma unroll
-            for (int g = 0; g < 2; ++g) na[g] = *reinterpret_cast<const u32x4 *>(gA + g * g32 + (uint64_t)qi * 128);
-#pragma unroll
-            for (int g = 0; g < 4; ++g) nb[g] = *reinterpret_cast<const u32x4 *>(gB + g * g32 + (uint64_t)qi * 128);
-        };
-        auto adopt = [&](uint32_t q4) {  // next quad -> current quad, window mask applied to A
-            const u32x4 m = {mask_of(q4), mask_of(q4 + 1), mask_of(q4 + 2), mask_of(q4 + 3)};
-#pragma unroll
-            for (int g = 0; g < 2; ++g) qa[g] = na[g] & m;  // a zero A byte kills the product
-#pragma unroll
-            for (int g = 0; g < 4; ++g) qb[g] = nb[g];
-        };
-        i32x4 fa[2], fb[4], ga[2], gb[4];
-        fetch(qbeg);
-        adopt(4 * qbeg);
-        fetch(qbeg + 1);
-#pragma unroll
-        for (int g = 0; g < 2; ++g) fa[g] = expand16(qa[g][0] >> sh, kmul);
-#pragma unroll
-        for (int g = 0; g < 4; ++g) fb[g] = expand16(qb[g][0] >> sh, kmul);
-        for (uint32_t qi = qbeg; qi < nq; ++qi) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                if (q == 3) {  // the step after this one starts the next quad (all-zero masks past the window)
-                    adopt(4 * qi + 4);
-                    if (qi + 2 < nq) fetch(qi + 2);
-                }
-                const int qn = (q + 1) & 3;
-#pragma unroll
-                for (int g = 0; g < 2; ++g) ga[g] = expand16(qa[g][qn] >> sh, kmul);
-#pragma unroll
-                for (int g = 0; g < 4; ++g) gb[g] = expand16(qb[g][qn] >> sh, kmul);
-#pragma unroll
-                for (int a = 0; a < 2; ++a)
-#pragma unroll
-                    for (int b = 0; b < 4; ++b)
-                        acc[a][b] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[a], fb[b], acc[a][b], 0, 0, 0);
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
-                    __builtin_amdgcn_sched_group_barrier(0x002, 10, 0);  // 10 VALU
-                }
-#pragma unroll
-                for (int g = 0; g < 2; ++g) fa[g] = ga[g];
-#pragma unroll
-                for (int g = 0; g < 4; ++g) fb[g] = gb[g];
-            }
-        }
-    }
     int32_t *o = out + (uint64_t)win * out_stride;
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < 4; ++b)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const uint32_t row = row0 + 32 * a + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
-                const uint32_t col = tj * GT + 32 * b + r32;
-                if (ksplit == 1) o[(uint64_t)row * ld + col] = acc[a][b][e];
-                else atomicAdd(&o[(uint64_t)row * ld + col], acc[a][b][e]);
-            }
+    if (ti == tj) gram_task<true>(rb, nb_row, ti, tj, wins[win], ks, ksplit, o, ld);
+    else gram_task<false>(rb, nb_row, ti, tj, wins[win], ks, ksplit, o, ld);
 }
 
 // mirror the upper tiles into the lower triangle (only for host export)
@@ -236,7 +239,7 @@ __global__ void pairwise_finalize_kernel(PairFinalIn in, uint64_t n_windows, uin
 
 static int launch_gram(impop_ctx *ctx, const impop_matrix *m, const GramWindow *d_wins, uint32_t n_win, int32_t *d_out) {
     const uint32_t T = m->n_hap_pad / GT;
-    const uint32_t tasks_per_win = T * (T + 1);  // upper-triangular tile pairs x 2 row halves
+    const uint32_t tasks_per_win = T * (T + 1) / 2;  // upper-triangular tile pairs
     uint64_t grid = (uint64_t)(n_win >= 8 ? (n_win + 7) / 8 * 8 : n_win) * tasks_per_win;
     // two waves per SIMD on every CU = 8 * n_cu resident waves; aim at >= 4 rounds of them so the
     // last, partially filled round does not dominate, and split the site axis when there are fewer tasks
@@ -247,7 +250,7 @@ static int launch_gram(impop_ctx *ctx, const impop_matrix *m, const GramWindow *
         HIP_TRY(hipMemsetAsync(d_out, 0, (size_t)n_win * m->n_hap_pad * m->n_hap_pad * sizeof(int32_t), ctx->stream));
     grid *= ksplit;
     REQUIRE(grid < 0x7FFFFFFFull, "gram: too many tasks for one launch");
-    hipLaunchKernelGGL(gram_mfma_kernel, dim3((uint32_t)grid), dim3(64), 0, ctx->stream, m->d_rb, m->rb_nq, T, tasks_per_win,
+    hipLaunchKernelGGL(gram_mfma_kernel, dim3((uint32_t)grid), dim3(64), 0, ctx->stream, m->d_rb, m->rb_nb, T, tasks_per_win,
                        n_win, ksplit, d_wins, d_out, m->n_hap_pad, (uint64_t)m->n_hap_pad * m->n_hap_pad);
     HIP_TRY(hipGetLastError());
     return IMPOP_OK;

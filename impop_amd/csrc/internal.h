@@ -77,6 +77,7 @@ struct impop_matrix {
     uint32_t n_hap_pad = 0;     // rows padded to a multiple of 96 (zero rows; Gram tiles are 96 wide)
     uint64_t rb_bytes = 0;
     int device = 0;
+    mutable int users = 0;      // live scan plans referencing this matrix (impop_matrix_free refuses while > 0)
 };
 
 namespace impop {

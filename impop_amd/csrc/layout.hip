@@ -354,6 +354,7 @@ IMPOP_API int impop_matrix_info(const impop_matrix *m, uint32_t *n_hap, uint64_t
 
 IMPOP_API int impop_matrix_free(impop_ctx *ctx, impop_matrix *m) {
     if (!m) return IMPOP_OK;
+    REQUIRE(m->users == 0, "impop_matrix_free: %d scan plan(s) still reference this matrix; destroy them first", m->users);
     if (ctx) {
         hipSetDevice(ctx->device);
         hipStreamSynchronize(ctx->stream);

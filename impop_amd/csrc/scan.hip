@@ -558,6 +558,7 @@ IMPOP_API int impop_scan_plan_create(impop_ctx *ctx, const impop_matrix *m, cons
     HIP_TRY(hipSetDevice(ctx->device));
     impop_scan_plan *p = new impop_scan_plan();
     p->ctx = ctx; p->m = m; p->n_windows = n_windows;
+    m->users++;
     p->d_pi_mode = prm.d_pi_mode; p->s_scope = prm.s_scope;
     const uint32_t n = m->g.n_hap, wps = m->g.wps;
     // masks; overlap of A and B is removed from both (h-fst.py:181-185)
@@ -700,6 +701,7 @@ IMPOP_API int impop_scan_plan_destroy(impop_scan_plan *p) {
     if (p->d_wins) hipFree(p->d_wins);
     if (p->d_out) hipFree(p->d_out);
     if (p->d_masks) hipFree(p->d_masks);
+    if (p->m) p->m->users--;
     delete p;
     return IMPOP_OK;
 }

@@ -244,8 +244,9 @@ class BitMatrix:
         return self._h
 
     def free(self) -> None:
+        """Release the device memory.  Raises if scan plans created from this matrix are still alive."""
         if self._h:
-            self.ctx._lib.impop_matrix_free(self.ctx.handle if self.ctx._h else None, self._h)
+            check(self.ctx._lib.impop_matrix_free(self.ctx.handle if self.ctx._h else None, self._h))
             self._h = C.c_void_p()
 
     def __del__(self):

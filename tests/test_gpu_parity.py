@@ -433,3 +433,24 @@ def test_afs_matches_numpy(ctx):
             assert (g == np.bincount(c, minlength=nP + 1)).all()
             assert int(g.sum()) == s1 - s0
     bm.free()
+
+
+def test_matrix_free_refused_while_plan_alive(ctx):
+    import impop_amd
+    bm = ctx.synthetic(64, 1000, seed=1)
+    plan = bm.plan([(0, 1000)])
+    with pytest.raises(impop_amd.ImpopError):
+        bm.free()
+    plan.launch()
+    assert int(plan.fetch()[0]["n_sites"]) == 1000
+    plan.destroy()
+    bm.free()
+    # argument validation surfaces as errors, not faults
+    bm = ctx.synthetic(64, 1000, seed=1)
+    with pytest.raises(impop_amd.ImpopError):
+        bm.scan([(0, 2000)])
+    with pytest.raises(impop_amd.ImpopError):
+        bm.scan([(10, 5)])
+    with pytest.raises(impop_amd.ImpopError):
+        bm.pairwise_counts(0, 1000)  # created without the haplotype-major copy
+    bm.free()

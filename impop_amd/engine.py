@@ -89,7 +89,7 @@ def make_windows(windows) -> np.ndarray:
     out = np.zeros(len(rows), dtype=WINDOW_DTYPE)
     for i, r in enumerate(rows):
         out[i]["site_begin"], out[i]["site_end"] = int(r[0]), int(r[1])
-        out[i]["seq_len"] = int(r[2]) if len(r) > 2 and r[2] is not None else int(r[1]) - int(r[0])
+        out[i]["seq_len"] = int(r[2]) if len(r) > 2 and r[2] is not None else max(int(r[1]) - int(r[0]), 0)
     return out
 
 

@@ -454,3 +454,45 @@ def test_matrix_free_refused_while_plan_alive(ctx):
     with pytest.raises(impop_amd.ImpopError):
         bm.pairwise_counts(0, 1000)  # created without the haplotype-major copy
     bm.free()
+
+
+def test_fuzz_scan_and_gram_random_shapes(ctx, oracle):
+    """Seeded fuzz: random haplotype counts (incl. 1, 31, 32, 33, 64, 96, 97 ...), site counts below and
+    above a 64-site block, random masks (empty / full / overlapping A and B), random ragged windows,
+    random tile sizes: integers bit-exact against the oracle, doubles within 1e-9."""
+    rng = np.random.default_rng(20251031)
+    special_n = [1, 2, 31, 32, 33, 63, 64, 65, 95, 96, 97, 128, 129, 191, 192, 193, 465, 512, 513]
+    for it in range(40):
+        n = int(special_n[it % len(special_n)] if it < 2 * len(special_n) else rng.integers(1, 700))
+        W = int(rng.choice([1, 5, 63, 64, 65, 127, 128, 129, 500, 1000, 2049, 3000]))
+        dens = float(rng.choice([0.0, 0.02, 0.3, 0.5, 1.0]))
+        m = (rng.random((n, W)) < dens).astype(np.uint8)
+        bits = oracle.pack_hap_major(m)
+        bm = ctx.upload(bits, W, keep_hap_major=True)
+        def rmask():
+            k = rng.integers(0, 4)
+            if k == 0:
+                return np.zeros(n, np.uint8)
+            if k == 1:
+                return np.ones(n, np.uint8)
+            return (rng.random(n) < rng.random()).astype(np.uint8)
+        inP, inA, inB = rmask(), rmask(), rmask()
+        if not inP.any():
+            inP[rng.integers(0, n)] = 1
+        wins = []
+        for _ in range(6):
+            a, b = sorted(int(x) for x in rng.integers(0, W + 1, size=2))
+            wins.append((a, b, int(rng.choice([0, 1, b - a if b > a else 3, 50000]))))
+        wins.append((0, W, W))
+        tb = int(rng.choice([0, 1, 2, 7, 64]))
+        dmode, sscope = int(rng.integers(0, 3)), int(rng.integers(0, 2))
+        got = bm.scan(wins, inP, inA, inB, d_pi_mode=dmode, s_scope=sscope, tile_blocks=tb)
+        for (s0, s1, sl), r in zip(wins, got):
+            want = oracle.window_sitecount(bits, n, s0, s1, oracle.pack_mask(inP), oracle.pack_mask(inA), oracle.pack_mask(inB),
+                                           sl, dmode, sscope)
+            check_record(r, want, ("fuzz", it, n, W, s0, s1, tb))
+        # Gram on two random windows (incl. possibly empty)
+        for (s0, s1, _) in wins[:2] + [wins[-1]]:
+            I = bm.pairwise_counts(s0, s1)
+            assert (I.astype(np.int64) == oracle.pairwise_counts(bits, n, s0, s1)).all(), ("gram", it, n, W, s0, s1)
+        bm.free()

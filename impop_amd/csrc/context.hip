@@ -120,6 +120,7 @@ IMPOP_API int impop_ctx_destroy(impop_ctx *ctx) {
     hipSetDevice(ctx->device);
     hipStreamSynchronize(ctx->stream);
     if (ctx->d_taj) hipFree(ctx->d_taj);
+    if (ctx->d_queue) hipFree(ctx->d_queue);
     if (ctx->scratch) hipFree(ctx->scratch);
     if (ctx->own_stream) hipStreamDestroy(ctx->stream);
     delete ctx;

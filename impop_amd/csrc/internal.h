@@ -59,6 +59,7 @@ struct impop_ctx {
     // cached Tajima constants on the device, keyed by n (8 doubles: a1,a2,b1,b2,c1,c2,e1,e2)
     double *d_taj = nullptr;
     int64_t taj_n = -1;
+    uint32_t *d_queue = nullptr;  // 8 task-queue heads of the persistent Gram kernel
     // growable scratch
     void *scratch = nullptr;
     size_t scratch_bytes = 0;

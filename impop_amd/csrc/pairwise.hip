@@ -4,6 +4,7 @@
 //
 // This path is VALU-bound, not HBM-bound: its roof is the popcount issue rate
 // (2 lane-ops per haplotype pair per 32 sites), reported separately from the scan.
+#include <algorithm>
 #include <vector>
 
 #include "stats_kernels.h"
@@ -36,6 +37,9 @@ namespace impop {
 // (expand step t+1 under the MFMAs of step t) and the sched_group_barrier issue pattern.
 // Both MFMA operands use the same (lane>>5, byte) -> site mapping, so the result does not depend
 // on the instruction's internal k order; C/D map: col = lane&31, row = (reg&3)+8(reg>>2)+4(lane>>5).
+#ifndef IMPOP_GRAM_ABLATE
+#define IMPOP_GRAM_ABLATE 0  // timing-only ablation builds (tools/): bit 0 no lookups, bit 1 no global loads, bit 2 no MFMA
+#endif
 constexpr int GT = 96;  // tile edge (haplotypes): 3 row groups of 32
 
 struct GramWindow {
@@ -77,13 +81,21 @@ __device__ __forceinline__ i32x4 expand16(uint32_t xs /* the lane's 16 bits in t
 // expansions per MFMA is the lever (96 also pads 465 haplotypes to 480 instead of 512).
 // Pipeline (no register copies): the two 64-site cells PA / PB alternate, fragments F / G alternate;
 // a cell is reloaded right after its last use, three steps before its next use.
+// Expansion by table: the 8 sites of one byte become 8 int8 through ONE conflict-free ds_read_b64.
+// The table is laid out [entry 0..255][lane slot 0..31] x 8 bytes (64 KB per workgroup): a lane only
+// ever reads its own slot column, so the 32 lanes of a half-wave always hit 32 different bank
+// pairs whatever their entries are.  The LDS address (entry << 8 | slot << 3) is formed by one
+// v_perm_b32 of the data dword with a per-lane constant: 1 VALU + 1 LDS read per 8 sites instead of
+// 6 VALU, which is what lifts the kernel off the VALU issue limit.
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
 template <bool DIAG>
 __device__ __forceinline__ void gram_task(const uint32_t *__restrict__ rb, uint64_t nb_row, uint32_t ti, uint32_t tj,
                                           const GramWindow w, uint32_t ks, uint32_t ksplit, int32_t *__restrict__ o,
-                                          uint32_t ld) {
+                                          uint32_t ld, const unsigned char *__restrict__ lut) {
     constexpr int NB = DIAG ? 0 : 3;  // B row groups to load (diagonal: reuse A)
-    const uint32_t lane = threadIdx.x & 63, r32 = lane & 31, sh = 16 * (lane >> 5);
-    const uint32_t kmul = 0x204081u;
+    const uint32_t lane = threadIdx.x & 63, r32 = lane & 31, hi_half = lane >> 5;
+    const uint32_t slot = r32 << 3;   // byte 0 of the v_perm source: this lane's 8-byte column in every table row
     i32x16 acc[3][3];
 #pragma unroll
     for (int a = 0; a < 3; ++a)
@@ -111,21 +123,49 @@ __device__ __forceinline__ void gram_task(const uint32_t *__restrict__ rb, uint6
         const uint32_t *gA = rb + (((uint64_t)(ti * 3) * nb_row + cell0) * 32 + r32) * 2;
         const uint32_t *gB = rb + (((uint64_t)(tj * 3) * nb_row + cell0) * 32 + r32) * 2;
         const uint64_t g32 = nb_row * 64;  // dwords between consecutive 32-row groups
-        typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-        u32x2 PA_a[3], PB_a[3], PA_b[3], PB_b[3];
-        auto load_cell = [&](u32x2 (&ca)[3], u32x2 (&cb)[3], uint32_t c) {  // slack cells keep this in bounds
+        // A 64-site cell is two dwords; lane half 0 works on dword 0, lane half 1 on dword 1, and the
+        // cell's two 32-site MFMA steps take bytes {0,1} then {2,3} of that dword: every site of the
+        // cell is used exactly once, identically for the A and the B operand (the order of sites
+        // inside a sum is irrelevant), and no per-lane shift is needed.
+        // The window mask of a cell is kept in its own register and applied when the cell is EXPANDED:
+        // masking at load time (`load & m`) makes the load's first use immediate and the compiler
+        // then waits vmcnt(0) right behind the prefetch (seen in the ISA), which serialises it.
+        uint32_t PA_a[3], PB_a[3], PA_b[3], PB_b[3], PA_m, PB_m;
+        const uint32_t hsel = hi_half ? 0xFFFFFFFFu : 0u;
+        auto load_cell = [&](uint32_t (&ca)[3], uint32_t (&cb)[3], uint32_t &cm, uint32_t c) {  // slack cells keep this in bounds
+            const uint32_t m0 = mask_of(2 * c), m1 = mask_of(2 * c + 1);
+            cm = (hsel & m1) | (~hsel & m0);  // v_bfi: lane half 1 works on dword 1 (masking A suffices)
+#if IMPOP_GRAM_ABLATE & 2  // timing-only build: no global loads
 #pragma unroll
-            for (int g = 0; g < 3; ++g) ca[g] = *reinterpret_cast<const u32x2 *>(gA + g * g32 + (uint64_t)c * 64);
+            for (int g = 0; g < 3; ++g) ca[g] = c * 2654435761u + g + lane;
 #pragma unroll
-            for (int g = 0; g < NB; ++g) cb[g] = *reinterpret_cast<const u32x2 *>(gB + g * g32 + (uint64_t)c * 64);
+            for (int g = 0; g < NB; ++g) cb[g] = c * 40503u + g + lane;
+            return;
+#endif
+#pragma unroll
+            for (int g = 0; g < 3; ++g) ca[g] = gA[g * g32 + (uint64_t)c * 64 + hi_half];
+#pragma unroll
+            for (int g = 0; g < NB; ++g) cb[g] = gB[g * g32 + (uint64_t)c * 64 + hi_half];
         };
         i32x4 Fa[3], Fb[3], Ga[3], Gb[3];
-        auto expand_step = [&](i32x4 (&fa)[3], i32x4 (&fb)[3], const u32x2 (&ca)[3], const u32x2 (&cb)[3], int half, uint32_t d) {
-            const uint32_t m = mask_of(d);  // masking A suffices: a zero byte kills the product
+        auto lookup16 = [&](uint32_t x, int half) -> i32x4 {  // bytes {2*half, 2*half+1} of x -> 16 int8
+#if IMPOP_GRAM_ABLATE & 1  // timing-only build: no v_perm / LDS reads (results are wrong)
+            i32x4 q = {(int)x, (int)(x + half), (int)x, (int)x};
+            return q;
+#endif
+            const uint32_t a0 = __builtin_amdgcn_perm(x, slot, half ? 0x0C0C0600u : 0x0C0C0400u);
+            const uint32_t a1 = __builtin_amdgcn_perm(x, slot, half ? 0x0C0C0700u : 0x0C0C0500u);
+            const u32x2 lo = *reinterpret_cast<const u32x2 *>(lut + a0);
+            const u32x2 hi = *reinterpret_cast<const u32x2 *>(lut + a1);
+            i32x4 r = {(int)lo.x, (int)lo.y, (int)hi.x, (int)hi.y};
+            return r;
+        };
+        auto expand_step = [&](i32x4 (&fa)[3], i32x4 (&fb)[3], const uint32_t (&ca)[3], const uint32_t (&cb)[3], uint32_t cm,
+                               int half) {
 #pragma unroll
-            for (int g = 0; g < 3; ++g) fa[g] = expand16(((half ? ca[g].y : ca[g].x) & m) >> sh, kmul);
+            for (int g = 0; g < 3; ++g) fa[g] = lookup16(ca[g] & cm, half);
 #pragma unroll
-            for (int g = 0; g < NB; ++g) fb[g] = expand16((half ? cb[g].y : cb[g].x) >> sh, kmul);
+            for (int g = 0; g < NB; ++g) fb[g] = lookup16(cb[g], half);
         };
         auto mfma_step = [&](const i32x4 (&fa)[3], const i32x4 (&fb)[3]) {
 #pragma unroll
@@ -133,24 +173,47 @@ __device__ __forceinline__ void gram_task(const uint32_t *__restrict__ rb, uint6
 #pragma unroll
                 for (int b = 0; b < 3; ++b) {
                     if (DIAG && b < a) continue;  // strictly below the block diagonal: by symmetry
+#if IMPOP_GRAM_ABLATE & 4  // timing-only build: no MFMA (operands kept alive)
+                    asm volatile("" ::"v"(fa[a]), "v"(DIAG ? fa[b] : fb[b]));
+                    continue;
+#endif
                     acc[a][b] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[a], DIAG ? fa[b] : fb[b], acc[a][b], 0, 0, 0);
                 }
         };
-        load_cell(PA_a, PA_b, cbeg);
-        load_cell(PB_a, PB_b, cbeg + 1);
-        expand_step(Fa, Fb, PA_a, PA_b, 0, 2 * cbeg);
+        load_cell(PA_a, PA_b, PA_m, cbeg);
+        load_cell(PB_a, PB_b, PB_m, cbeg + 1);
+        expand_step(Fa, Fb, PA_a, PA_b, PA_m, 0);
+        // Inside a phase: first the address perms and the LDS look-ups of the NEXT step (their latency
+        // then hides under this phase's MFMAs, whose own operands were read one phase ago), then the
+        // MFMAs; the closing sched_barrier stops any motion across phases.
+#define PHASE_ORDER()                                                                      \
+    do {                                                                                   \
+        __builtin_amdgcn_sched_group_barrier(0x002, DIAG ? 9 : 15, 0);  /* VALU: and + perm */ \
+        __builtin_amdgcn_sched_group_barrier(0x100, DIAG ? 6 : 12, 0);  /* DS reads */     \
+        __builtin_amdgcn_sched_group_barrier(0x008, DIAG ? 6 : 9, 0);   /* MFMA */         \
+        __builtin_amdgcn_sched_barrier(0);                                                 \
+    } while (0)
+        // Four phases per iteration; sched_barrier keeps the compiler from pulling a later phase's
+        // expansion (and with it the vmcnt wait on the cell just prefetched) forward: without it the
+        // ISA showed vmcnt(0) a few instructions behind the loads.  Inside a phase the 12 LDS look-ups
+        // of the NEXT step and the 9 MFMAs of the CURRENT step are free to interleave.
         for (uint32_t c = cbeg; c < cend; c += 2) {
-            expand_step(Ga, Gb, PA_a, PA_b, 1, 2 * c + 1);   // cell c, second dword: last use of PA
-            load_cell(PA_a, PA_b, c + 2);
+            expand_step(Ga, Gb, PA_a, PA_b, PA_m, 1);   // cell c, second half: last use of PA
+            load_cell(PA_a, PA_b, PA_m, c + 2);         // reloaded 3 phases before its next use
             mfma_step(Fa, Fb);
-            expand_step(Fa, Fb, PB_a, PB_b, 0, 2 * c + 2);   // cell c+1 (zero mask if past the slice)
+            PHASE_ORDER();
+            expand_step(Fa, Fb, PB_a, PB_b, PB_m, 0);   // cell c+1 (all-zero A if past the slice)
             mfma_step(Ga, Gb);
-            expand_step(Ga, Gb, PB_a, PB_b, 1, 2 * c + 3);   // last use of PB
-            load_cell(PB_a, PB_b, c + 3);
+            PHASE_ORDER();
+            expand_step(Ga, Gb, PB_a, PB_b, PB_m, 1);   // last use of PB
+            load_cell(PB_a, PB_b, PB_m, c + 3);
             mfma_step(Fa, Fb);
-            expand_step(Fa, Fb, PA_a, PA_b, 0, 2 * c + 4);   // cell c+2 for the next iteration
+            PHASE_ORDER();
+            expand_step(Fa, Fb, PA_a, PA_b, PA_m, 0);   // cell c+2 for the next iteration
             mfma_step(Ga, Gb);
+            PHASE_ORDER();
         }
+#undef PHASE_ORDER
     }
 #pragma unroll
     for (int a = 0; a < 3; ++a)
@@ -167,34 +230,55 @@ __device__ __forceinline__ void gram_task(const uint32_t *__restrict__ rb, uint6
         }
 }
 
-// grid: 1-D, tasks = (window, tile pair) x K-slice.  Consecutive block ids are dealt round-robin
-// over the 8 XCDs, so id % 8 selects the window inside a group of 8 windows: all tasks of one
-// window then share one XCD's L2 (speed only; any placement is correct).
-// ksplit > 1: the site range of a window is cut into ksplit slices handled by different waves that
+// Persistent workgroups (2 per CU, 4 waves each) that share only the lookup table; every WAVE pulls
+// (window, tile pair, K-slice) tasks from one of 8 queues until all are drained, so a wave whose task
+// was short (diagonal tiles do 2/3 of the MFMAs) immediately starts another one and both SIMD slots
+// stay occupied (PMC before this change: 1.45-1.6 resident waves per SIMD, after: ~2).
+// Queue q holds the tasks of windows with win % 8 == q and is served first by workgroups with
+// blockIdx % 8 == q, i.e. (under the observed round-robin placement) by one XCD, whose L2 then holds
+// that window's rows for all of its 15 tile pairs; a workgroup whose queue is empty steals from the
+// others, so the result and termination never depend on placement: every wave leaves once all eight
+// counters have passed their queue length.
+// ksplit > 1: the site range of a window is cut into ksplit slices handled by different tasks that
 // atomicAdd into a zero-initialised output (integer adds commute: still bit-reproducible); used
-// when there are too few (window, tile) tasks to put two waves on every SIMD.
-__global__ __launch_bounds__(64, 2) void gram_mfma_kernel(const uint32_t *__restrict__ rb, uint64_t nb_row,
-                                                          uint32_t n_tiles, uint32_t tasks_per_win, uint32_t n_win,
-                                                          uint32_t ksplit, const GramWindow *__restrict__ wins,
-                                                          int32_t *__restrict__ out, uint32_t ld, uint64_t out_stride) {
-    const uint32_t ks = blockIdx.x % ksplit;
-    const uint32_t id = blockIdx.x / ksplit;
-    uint32_t win, task;
-    if (n_win >= 8) {
-        const uint32_t grp = id / (8 * tasks_per_win), within = id % (8 * tasks_per_win);
-        win = grp * 8 + (within & 7);
-        task = within >> 3;
-        if (win >= n_win) return;
-    } else {  // few windows: spread each window's tasks over all XCDs instead
-        win = id / tasks_per_win;
-        task = id % tasks_per_win;
+// when there are too few (window, tile) tasks to keep two waves on every SIMD.
+__global__ __launch_bounds__(256, 2) void gram_mfma_kernel(const uint32_t *__restrict__ rb, uint64_t nb_row,
+                                                           uint32_t n_tiles, uint32_t tasks_per_win, uint32_t n_win,
+                                                           uint32_t ksplit, const GramWindow *__restrict__ wins,
+                                                           int32_t *__restrict__ out, uint32_t ld, uint64_t out_stride,
+                                                           uint32_t *__restrict__ queue_heads /* 8, zeroed per launch */) {
+    __shared__ __attribute__((aligned(16))) unsigned char lut[256 * 32 * 8];  // 64 KB: [entry][lane slot] x 8 bytes
+    for (uint32_t i = threadIdx.x; i < 256 * 32; i += 256) {
+        const uint32_t e = i >> 5;  // entry: bit j of e -> byte j
+        u32x2 v;
+        v.x = __umul24(e & 0xFu, 0x204081u) & 0x01010101u;
+        v.y = __umul24((e >> 4) & 0xFu, 0x204081u) & 0x01010101u;
+        *reinterpret_cast<u32x2 *>(lut + (size_t)i * 8) = v;
     }
-    uint32_t rem = task, ti = 0;
-    while (rem >= n_tiles - ti) { rem -= n_tiles - ti; ++ti; }
-    const uint32_t tj = ti + rem;
-    int32_t *o = out + (uint64_t)win * out_stride;
-    if (ti == tj) gram_task<true>(rb, nb_row, ti, tj, wins[win], ks, ksplit, o, ld);
-    else gram_task<false>(rb, nb_row, ti, tj, wins[win], ks, ksplit, o, ld);
+    __syncthreads();  // the only barrier; everything below is per wave
+    const uint32_t slots = tasks_per_win * ksplit;  // (tile pair, K-slice) slots of one window
+    const bool by_window = n_win >= 8;              // few windows: deal single tasks round-robin instead
+    const uint64_t total = (uint64_t)n_win * slots;
+    for (uint32_t dq = 0; dq < 8; ++dq) {
+        const uint32_t q = (blockIdx.x + dq) & 7;
+        const uint64_t q_len = by_window ? (uint64_t)((n_win + 7 - q) / 8) * slots : (total + 7 - q) / 8;
+        for (;;) {
+            uint32_t k = 0;
+            if ((threadIdx.x & 63) == 0) k = atomicAdd(&queue_heads[q], 1u);
+            k = __builtin_amdgcn_readfirstlane(k);
+            if (k >= q_len) break;  // queue drained (the head keeps counting, harmlessly)
+            uint32_t win, t2;
+            if (by_window) { win = q + 8 * (k / slots); t2 = k % slots; }
+            else { const uint64_t i = q + 8ull * k; win = (uint32_t)(i / slots); t2 = (uint32_t)(i % slots); }
+            const uint32_t ks = t2 % ksplit;
+            uint32_t rem = t2 / ksplit, ti = 0;
+            while (rem >= n_tiles - ti) { rem -= n_tiles - ti; ++ti; }
+            const uint32_t tj = ti + rem;
+            int32_t *o = out + (uint64_t)win * out_stride;
+            if (ti == tj) gram_task<true>(rb, nb_row, ti, tj, wins[win], ks, ksplit, o, ld, lut);
+            else gram_task<false>(rb, nb_row, ti, tj, wins[win], ks, ksplit, o, ld, lut);
+        }
+    }
 }
 
 // mirror the upper tiles into the lower triangle (only for host export)
@@ -240,18 +324,22 @@ __global__ void pairwise_finalize_kernel(PairFinalIn in, uint64_t n_windows, uin
 static int launch_gram(impop_ctx *ctx, const impop_matrix *m, const GramWindow *d_wins, uint32_t n_win, int32_t *d_out) {
     const uint32_t T = m->n_hap_pad / GT;
     const uint32_t tasks_per_win = T * (T + 1) / 2;  // upper-triangular tile pairs
-    uint64_t grid = (uint64_t)(n_win >= 8 ? (n_win + 7) / 8 * 8 : n_win) * tasks_per_win;
     // two waves per SIMD on every CU = 8 * n_cu resident waves; aim at >= 4 rounds of them so the
     // last, partially filled round does not dominate, and split the site axis when there are fewer tasks
     const uint64_t want = 32ull * (uint64_t)(ctx->n_cu > 0 ? ctx->n_cu : 256);
     uint32_t ksplit = 1;
-    while (grid * ksplit < want && ksplit < 64) ksplit *= 2;
+    while ((uint64_t)n_win * tasks_per_win * ksplit < want && ksplit < 64) ksplit *= 2;
     if (ksplit > 1)
         HIP_TRY(hipMemsetAsync(d_out, 0, (size_t)n_win * m->n_hap_pad * m->n_hap_pad * sizeof(int32_t), ctx->stream));
-    grid *= ksplit;
-    REQUIRE(grid < 0x7FFFFFFFull, "gram: too many tasks for one launch");
-    hipLaunchKernelGGL(gram_mfma_kernel, dim3((uint32_t)grid), dim3(64), 0, ctx->stream, m->d_rb, m->rb_nb, T, tasks_per_win,
-                       n_win, ksplit, d_wins, d_out, m->n_hap_pad, (uint64_t)m->n_hap_pad * m->n_hap_pad);
+    REQUIRE((uint64_t)n_win * tasks_per_win * ksplit < 0xFFFFFFF0ull, "gram: too many tasks for one launch");
+    if (!ctx->d_queue) HIP_TRY(hipMalloc((void **)&ctx->d_queue, 8 * sizeof(uint32_t)));
+    HIP_TRY(hipMemsetAsync(ctx->d_queue, 0, 8 * sizeof(uint32_t), ctx->stream));
+    // persistent grid: two 256-thread workgroups per CU (64 KB of LDS each), never fewer than 8
+    const uint32_t n_cu = (uint32_t)(ctx->n_cu > 0 ? ctx->n_cu : 256);
+    const uint64_t need_wg = ((uint64_t)n_win * tasks_per_win * ksplit + 3) / 4;
+    const uint32_t grid = (uint32_t)std::max<uint64_t>(8, std::min<uint64_t>(2ull * n_cu, need_wg));
+    hipLaunchKernelGGL(gram_mfma_kernel, dim3(grid), dim3(256), 0, ctx->stream, m->d_rb, m->rb_nb, T, tasks_per_win, n_win,
+                       ksplit, d_wins, d_out, m->n_hap_pad, (uint64_t)m->n_hap_pad * m->n_hap_pad, ctx->d_queue);
     HIP_TRY(hipGetLastError());
     return IMPOP_OK;
 }

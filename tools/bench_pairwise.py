@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--window", type=int, default=50000)
     ap.add_argument("--big-hap", type=int, default=4096)
     ap.add_argument("--big-sites", type=int, default=1_000_000)
+    ap.add_argument("--no-check", action="store_true", help="ablation builds produce wrong results")
     args = ap.parse_args()
     import numpy as np
     import impop_amd
@@ -46,7 +47,7 @@ def main():
     bits = bm.download(0, W)
     sim = orc.identity(orc.pairwise_counts(bits, n, 0, W), W, 0)
     pi, ps, _, G = orc.pica2(sim, 0.999, W, 5)
-    assert abs(float(res[0]["pi"]) - pi) <= 1e-9 * abs(pi) and int(res[0]["n_groups"]) == G, (res[0], pi, G)
+    assert args.no_check or (abs(float(res[0]["pi"]) - pi) <= 1e-9 * abs(pi) and int(res[0]["n_groups"]) == G), (res[0], pi, G)
     pair_words = (n * (n + 1) // 2) * ((W + 31) // 32)
     out["pairwise_scan_465x50kb"] = {"windows": NW, "s_per_batch": dt, "windows_per_s": NW / dt, "groups_window0": G,
                                      "algorithmic_lane_ops_per_window": 2 * pair_words}
@@ -64,7 +65,7 @@ def main():
     Ic = bm.pairwise_counts(0, min(Wb, 200000))
     idx = [0, 1, 63, 64, 127, 128, 1000, nb - 1]
     want = m[idx] @ m.T
-    assert (Ic[idx].astype(np.int64) == want).all()
+    assert args.no_check or (Ic[idx].astype(np.int64) == want).all()
     pair_words = (nb * (nb + 1) // 2) * ((Wb + 31) // 32)
     out["gram_%dx%d" % (nb, Wb)] = {"s_incl_copy_out": dt, "algorithmic_lane_ops": 2 * pair_words,
                                     "lane_ops_per_s_incl_copy": 2 * pair_words / dt,

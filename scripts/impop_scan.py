@@ -53,7 +53,8 @@ def main():
     ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
     ap.add_argument("--matrix", required=True, help=".npz presence matrix (impop_amd.matrixio)")
     ap.add_argument("--bed", "-b", required=True)
-    ap.add_argument("--format", choices=["pica2", "hfst", "tajd", "all"], default="all")
+    ap.add_argument("--format", choices=["pica2", "hfst", "tajd", "fst3pi", "all"], default="all",
+                    help="fst3pi = the 3 x pi table of run_fst_impg.sh (needs -A and -B, disjoint)")
     ap.add_argument("-A", "--pop-a"); ap.add_argument("-B", "--pop-b")
     ap.add_argument("--panel", nargs="+", metavar="POP.txt", help="hfst: K >= 2 disjoint population lists; every pair "
                     "in ONE pass (replaces run_h_fst_panels.sh); one table per pair, labelled POP_A-vs-POP_B")
@@ -176,6 +177,19 @@ def main():
         for reg, (b, e, L), r in zip(regions, wins, res):
             print(f"{reg}\t{L}\t{float(r['fst']):.8f}\t{float(r['pi_a']):.8f}\t{float(r['pi_b']):.8f}\t"
                   f"{float(r['pi_xy']):.8f}\t{float(r['dxy']):.8f}\t{float(r['da']):.8f}", file=out)
+    if fmt == "fst3pi":
+        from impop_amd.drivers import fst_3pi_fields, pi_union_site
+        if mask_a is None:
+            print("Error: --format fst3pi needs -A and -B", file=sys.stderr)
+            sys.exit(2)
+        if (mask_a & mask_b).any():
+            print("Error: --format fst3pi needs disjoint populations", file=sys.stderr)
+            sys.exit(2)
+        nA, nB = int(mask_a.sum()), int(mask_b.sum())
+        print("REGION\tLENGTH\tTHRESHOLD\tR_VALUE\tPI_A\tPI_B\tPI_C\tPI_AB_AVG\tFST", file=out)  # run_fst_impg.sh:158
+        for reg, (b, e, L), r in zip(regions, wins, res):
+            ta, tb, tc, avg, fst = fst_3pi_fields(float(r["pi_a"]), float(r["pi_b"]), pi_union_site(r, nA, nB, L))
+            print(f"{reg}\t{L}\t{thr_txt}\t{r_txt}\t{ta}\t{tb}\t{tc}\t{avg}\t{fst}", file=out)
     if fmt in ("tajd", "all"):
         print("REGION\tLENGTH\tSAMPLES\tSEGREGATING_SITES\tPI\tTAJIMAS_D", file=out)
         for reg, (b, e, L), r in zip(regions, wins, res):

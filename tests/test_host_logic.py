@@ -113,3 +113,15 @@ def test_window_helpers():
     assert mk.tolist() == [5, 2] and impop_amd.mask_from_indices([0, 2, 65], 66).tolist() == [5, 2]
     mw = impop_amd.make_windows([(0, 10), (5, 20, 777)])
     assert mw["seq_len"].tolist() == [10, 777]
+
+
+def test_fst_3pi_known_answer():
+    """doc/how_fst.md:59-65: piA 0.00000279, piB 0.00000577, piC 0.00000528 -> 0.1893939 (run_fst_impg.sh:207-218)."""
+    from impop_amd.drivers import fst_3pi_fields, pi_union_site, pica_cell
+    ta, tb, tc, avg, fst = fst_3pi_fields(0.00000279, 0.00000577, 0.00000528)
+    assert (ta, tb, tc, avg) == ("0.00000279", "0.00000577", "0.00000528", "0.00000428")
+    assert fst == "0.18939394" and abs(float(fst) - 0.1893939) < 1e-7
+    assert fst_3pi_fields(0.1, 0.2, 0.0)[4] == "NA"
+    assert pica_cell(2.093e-05, 1000) == "0.00002093 (sequence length: 1000)"
+    rec = {"n_sites": 100, "sum_a": 30, "sum_b": 12, "sum_ab": 58}
+    assert pi_union_site(rec, 3, 2, 100) == 100 / (10.0 * 100) / 100

@@ -56,6 +56,22 @@ def test_batch_driver_tables(tmp_path, oracle):
         # D is printed with repr(); n = 12 list lines (run_tajd.sh:83) => recompute through the oracle
         D, _ = oracle.tajimas_d(n, float(w["s_all"]), oracle.py_round(w["pi_site"], 8))
         assert abs(float(t[5]) - D) <= 1e-9 * abs(D)
+    # 3 x pi table (run_fst_impg.sh): PI_C = pica2 on the union list, here against the oracle's pica2
+    r3 = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "impop_scan.py"), "--matrix", str(tmp_path / "m.npz"),
+                         "--bed", str(tmp_path / "w.bed"), "--format", "fst3pi", "-A", str(tmp_path / "A.txt"), "-B", str(tmp_path / "B.txt")],
+                        capture_output=True, text=True)
+    assert r3.returncode == 0, r3.stderr
+    l3 = r3.stdout.strip().split("\n")
+    assert l3[0] == "REGION\tLENGTH\tTHRESHOLD\tR_VALUE\tPI_A\tPI_B\tPI_C\tPI_AB_AVG\tFST"  # run_fst_impg.sh:158
+    for k, (s0, s1, L, reg) in enumerate(wins):
+        sim = oracle.identity(oracle.pairwise_counts(bits, n, s0, s1), s1 - s0, 0)
+        t = l3[1 + k].split("\t")
+        for col, sel in ((4, inA), (5, inB), (6, inA | inB)):
+            idx = np.nonzero(sel)[0]
+            _, ps, _, _ = oracle.pica2(sim[np.ix_(idx, idx)], 1.0, L, None)
+            assert abs(float(t[col]) - ps) <= 1.0000001e-8, (reg, col, t[col], ps)
+        fa, fb, fc = float(t[4]), float(t[5]), float(t[6])
+        assert t[7] == f"{0.5 * (fa + fb):.8f}" and t[8] == ("NA" if fc == 0 else f"{(fc - 0.5 * (fa + fb)) / fc:.8f}")
     # thresholded pica2 goes through the all-pairs path
     r2 = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "impop_scan.py"), "--matrix", str(tmp_path / "m.npz"),
                          "--bed", str(tmp_path / "w.bed"), "--format", "pica2", "-t", "0.995", "-r", "4"], capture_output=True, text=True)

@@ -300,6 +300,7 @@ struct PairFinalIn {
     const impop_window_stats *scan;  // integer S / W from the site scan of the same windows
 };
 __global__ void pairwise_finalize_kernel(PairFinalIn in, uint64_t n_windows, uint32_t nP, int d_pi_mode, int s_scope,
+                                         const double *__restrict__ taj /* a1,a2,b1,b2,c1,c2,e1,e2 for n = nP */,
                                          impop_pairwise_stats *__restrict__ out) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_windows) return;
@@ -314,7 +315,8 @@ __global__ void pairwise_finalize_kernel(PairFinalIn in, uint64_t n_windows, uin
     const double pin = d_pi_mode == 0 ? py_round(p.pi_site, 8) : d_pi_mode == 1 ? p.pi_site : p.pi * (double)s.n_sites;
     double D = __builtin_nan("");
     if (nP >= 2 && pin == pin && pin >= 0) {
-        const TajConsts c = tajima_consts((int64_t)nP);
+        TajConsts c;
+        c.a1 = taj[0]; c.a2 = taj[1]; c.b1 = taj[2]; c.b2 = taj[3]; c.c1 = taj[4]; c.c2 = taj[5]; c.e1 = taj[6]; c.e2 = taj[7];
         D = tajima_d_from(c, S, pin, nullptr, nullptr);
     }
     r.tajima_d = D;
@@ -525,8 +527,10 @@ IMPOP_API int impop_pairwise_scan(impop_ctx *ctx, const impop_matrix *m, const i
         rc = launch_hfst(ctx, b, cnt, d_fa, d_fb, d_L, d_h);
         if (rc) return fail(rc);
         PairFinalIn in{d_p, d_h, d_s};
+        rc = ensure_tajima_consts(ctx, nP >= 2 ? (int64_t)nP : 2);  // the cache may have been retargeted by another plan
+        if (rc) return fail(rc);
         hipLaunchKernelGGL(pairwise_finalize_kernel, dim3((uint32_t)((cnt + 63) / 64)), dim3(64), 0, ctx->stream, in, cnt,
-                           nP, params->d_pi_mode, params->s_scope, d_o);
+                           nP, params->d_pi_mode, params->s_scope, ctx->d_taj, d_o);
         PW_TRY(hipGetLastError());
         PW_TRY(hipMemcpyAsync(out_host + base, d_o, cnt * sizeof(impop_pairwise_stats), hipMemcpyDeviceToHost, ctx->stream));
         PW_TRY(hipStreamSynchronize(ctx->stream));  // gw/Wv/Lv are reused by the next chunk

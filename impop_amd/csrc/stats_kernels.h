@@ -26,7 +26,31 @@ struct SimView {
     uint64_t W;
     int kind;
     int round_digits;
+    // optional memo in LDS for the `match` identity of a Gram problem: identity is a function of the
+    // Hamming distance H alone, so (W - H)/W and its CPython rounding are tabulated once per window
+    // for H < tbl_n (same arithmetic, hence bit-identical values) instead of once per pair
+    const double *tbl;
+    uint32_t tbl_n;
 };
+
+constexpr uint32_t SIM_TBL_N = 4096;
+
+__device__ inline double match_identity(uint64_t W, int64_t H, int round_digits) {
+    double v = W ? (double)((int64_t)W - H) / (double)W : 1.0;
+    if (round_digits >= 0) v = py_round(v, round_digits);
+    return v;
+}
+
+// cooperative fill by the whole workgroup (call before any sim_get; caller synchronises)
+__device__ inline void sim_table_fill(SimView &S, double *lds_tbl, uint32_t n_threads) {
+    S.tbl = nullptr;
+    S.tbl_n = 0;
+    if (S.gram && S.kind == IMPOP_IDENTITY_MATCH) {
+        for (uint32_t h = threadIdx.x; h < SIM_TBL_N; h += n_threads) lds_tbl[h] = match_identity(S.W, (int64_t)h, S.round_digits);
+        S.tbl = lds_tbl;
+        S.tbl_n = SIM_TBL_N;
+    }
+}
 
 __device__ inline SimView sim_view(const SimBatch &b, uint64_t p) {
     SimView v;
@@ -36,6 +60,8 @@ __device__ inline SimView sim_view(const SimBatch &b, uint64_t p) {
     v.W = b.W ? b.W[p] : 0;
     v.kind = b.kind;
     v.round_digits = b.round_digits;
+    v.tbl = nullptr;
+    v.tbl_n = 0;
     return v;
 }
 
@@ -50,6 +76,7 @@ __device__ inline double sim_get(const SimView &S, uint32_t i, uint32_t j) {
         const int64_t ai = S.gram[(uint64_t)i * S.ld + i], aj = S.gram[(uint64_t)j * S.ld + j];
         if (S.kind == IMPOP_IDENTITY_MATCH) {
             const int64_t H = ai + aj - 2 * I;
+            if ((uint64_t)H < S.tbl_n) return S.tbl[H];  // memoised (already rounded)
             v = S.W ? (double)((int64_t)S.W - H) / (double)S.W : 1.0;
         } else {
             const int64_t d = ai + aj;

@@ -45,10 +45,8 @@ __global__ __launch_bounds__(ST) void pica2_kernel(SimBatch batch, const uint32_
     uint32_t *rep = grp + n_el;
     uint32_t *gsz = rep + n_el;
     __shared__ uint32_t sh_have;
-    __shared__ double sim_tbl[SIM_TBL_N];
     const uint64_t prob = blockIdx.x;
-    SimView S = sim_view(batch, prob);
-    sim_table_fill(S, sim_tbl, ST);
+    const SimView S = sim_view(batch, prob);  // no identity memo here: with few groups it costs more than it saves
     const uint32_t tid = threadIdx.x;
     for (uint32_t i = tid; i < n_el; i += ST) { grp[i] = NONE; gsz[i] = 0; }
     if (tid == 0) sh_have = 0;
@@ -262,9 +260,9 @@ int launch_pica2(impop_ctx *ctx, const SimBatch &b, uint64_t n_problems, const u
                  double threshold, const uint64_t *d_seq_len, Pica2Out *d_out, uint32_t *d_group_of) {
     if (!n_problems) return IMPOP_OK;
     const size_t lds = (size_t)n_el * (8 + 12) + 16;
-    REQUIRE(lds <= 118 * 1024, "pica2: %u elements exceed the LDS-resident grouping limit (6000)", n_el);
+    REQUIRE(lds <= 150 * 1024, "pica2: %u elements exceed the LDS-resident grouping limit (7600)", n_el);
     REQUIRE(n_problems < 0x7FFFFFFFull, "pica2: too many problems");
-    if (lds > 16 * 1024)  // 32 KB of static LDS (identity memo) sit next to the dynamic part
+    if (lds > 48 * 1024)
         HIP_TRY(hipFuncSetAttribute((const void *)pica2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(pica2_kernel, dim3((uint32_t)n_problems), dim3(ST), lds, ctx->stream, b, d_idx, n_el, threshold,
                        d_seq_len, d_out, d_group_of);

@@ -3,6 +3,7 @@
 #include <math.h>
 #include <string.h>
 
+#include <algorithm>
 #include <vector>
 
 #include "stats_kernels.h"
@@ -153,6 +154,107 @@ __global__ __launch_bounds__(ST) void hfst_kernel(SimBatch batch, const uint8_t 
             o.v[0] = fst; o.v[1] = pi_a; o.v[2] = pi_b; o.v[3] = pi_xy; o.v[4] = dxy; o.v[5] = dxy - pi_xy;
         }
         o.cnt[0] = cA; o.cnt[1] = mA; o.cnt[2] = cB; o.cnt[3] = mB; o.cnt[4] = cX; o.cnt[5] = mX;
+        out[prob] = o;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// scripts/hudson/hud.py "grouped" Fst (hud.py:64-128, 173-300): greedy groups INSIDE each
+// population, frequency-weighted sums over group pairs with the first pair present in the table
+// (members in sorted order) as the groups' similarity.
+__device__ inline uint32_t hud_group(const SimView &S, const uint32_t *__restrict__ idx, uint32_t m, double thr,
+                                     uint32_t *grp, uint32_t *gsz) {
+    const uint32_t tid = threadIdx.x;
+    for (uint32_t i = tid; i < m; i += ST) { grp[i] = NONE; gsz[i] = 0; }
+    __syncthreads();
+    uint32_t G = 0;
+    for (uint32_t seed = 0; seed < m; ++seed) {
+        if (grp[seed] != NONE) continue;  // uniform
+        uint32_t cnt = 0;
+        if (tid == 0) { grp[seed] = G; cnt = 1; }
+        for (uint32_t o = seed + 1 + tid; o < m; o += ST) {
+            if (grp[o] != NONE) continue;
+            const double v = sim_get(S, idx[seed], idx[o]);
+            if (v == v && v > thr) { grp[o] = G; ++cnt; }  // hud.py:76-82
+        }
+        if (cnt) atomicAdd(&gsz[G], cnt);
+        ++G;
+        __syncthreads();
+    }
+    return G;
+}
+// hud.py:88-99 get_group_similarity: first (member of g1) x (member of g2) pair that is present
+__device__ inline double hud_first_found(const SimView &S, const uint32_t *ia, const uint32_t *ga, uint32_t ma, uint32_t g1,
+                                         const uint32_t *ib, const uint32_t *gb, uint32_t mb, uint32_t g2) {
+    for (uint32_t i = 0; i < ma; ++i) {
+        if (ga[i] != g1) continue;
+        for (uint32_t j = 0; j < mb; ++j) {
+            if (gb[j] != g2) continue;
+            const double v = sim_get(S, ia[i], ib[j]);
+            if (v == v) return v;
+        }
+    }
+    return __builtin_nan("");
+}
+// dynamic LDS: rowsum[max(ma,mb)] f64 | grpA[ma] | szA[ma] | grpB[mb] | szB[mb]
+__global__ __launch_bounds__(ST) void hud_grouped_kernel(SimBatch batch, const uint32_t *__restrict__ ia, uint32_t ma,
+                                                         const uint32_t *__restrict__ ib, uint32_t mb, double threshold,
+                                                         const uint64_t *__restrict__ seq_len, HfstOut *__restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    const uint32_t mx = ma > mb ? ma : mb;
+    double *rowsum = reinterpret_cast<double *>(lds_raw);
+    uint32_t *grpA = reinterpret_cast<uint32_t *>(rowsum + mx);
+    uint32_t *szA = grpA + ma, *grpB = szA + ma, *szB = grpB + mb;
+    __shared__ double sh_res[3];
+    __shared__ uint64_t sh_miss[3];
+    const uint64_t prob = blockIdx.x;
+    const SimView S = sim_view(batch, prob);
+    const uint32_t tid = threadIdx.x;
+    const uint32_t GA = hud_group(S, ia, ma, threshold, grpA, szA);
+    const uint32_t GB = hud_group(S, ib, mb, threshold, grpB, szB);
+    if (tid < 3) sh_miss[tid] = 0;
+    __syncthreads();
+    // within A, within B (hud.py:101-128), then between (hud.py:235-263): one pass each
+    for (int pass = 0; pass < 3; ++pass) {
+        const uint32_t *i1 = pass == 1 ? ib : ia, *g1 = pass == 1 ? grpB : grpA, *s1 = pass == 1 ? szB : szA;
+        const uint32_t *i2 = pass == 0 ? ia : ib, *g2 = pass == 0 ? grpA : grpB, *s2 = pass == 0 ? szA : szB;
+        const uint32_t m1 = pass == 1 ? mb : ma, m2 = pass == 0 ? ma : mb;
+        const uint32_t G1 = pass == 1 ? GB : GA, G2 = pass == 0 ? GA : GB;
+        uint64_t miss = 0;
+        for (uint32_t x = tid; x < G1; x += ST) {
+            double acc = 0.0;
+            for (uint32_t y = (pass == 2 ? 0 : x + 1); y < G2; ++y) {
+                const double sv = hud_first_found(S, i1, g1, m1, x, i2, g2, m2, y);
+                if (sv != sv) { ++miss; continue; }
+                if (pass == 2) acc += (((double)s1[x] * (double)s2[y]) / ((double)m1 * (double)m2)) * (1 - sv);  // :255-256
+                else acc += 2 * ((double)s1[x] / (double)m1) * ((double)s2[y] / (double)m2) * (1 - sv);        // :119-121
+            }
+            rowsum[x] = acc;
+        }
+        if (miss) atomicAdd((unsigned long long *)&sh_miss[pass], (unsigned long long)miss);
+        __syncthreads();
+        if (tid == 0) {
+            double acc = 0.0;
+            for (uint32_t x = 0; x < G1; ++x) acc += rowsum[x];
+            if (pass < 2) acc = (m1 <= 1) ? 0.0 : acc * (double)m1 / (double)(m1 - 1);  // :106-107, :127
+            sh_res[pass] = acc;
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        const double pi_a = sh_res[0], pi_b = sh_res[1], dxy = sh_res[2];
+        const double pi_xy = 0.5 * (pi_a + pi_b);
+        const double fst = (dxy > 0) ? (dxy - pi_xy) / dxy : 0.0;
+        const uint64_t L = seq_len ? seq_len[prob] : 0;
+        HfstOut o;
+        if (L > 0) {
+            const double dl = (double)L;
+            o.v[0] = fst; o.v[1] = pi_a / dl; o.v[2] = pi_b / dl; o.v[3] = pi_xy / dl; o.v[4] = dxy / dl; o.v[5] = (dxy - pi_xy) / dl;
+        } else {
+            o.v[0] = fst; o.v[1] = pi_a; o.v[2] = pi_b; o.v[3] = pi_xy; o.v[4] = dxy; o.v[5] = dxy - pi_xy;
+        }
+        o.cnt[0] = GA; o.cnt[1] = sh_miss[0]; o.cnt[2] = GB; o.cnt[3] = sh_miss[1];
+        o.cnt[4] = (uint64_t)GA * GB - sh_miss[2]; o.cnt[5] = sh_miss[2];
         out[prob] = o;
     }
 }
@@ -479,5 +581,49 @@ IMPOP_API int impop_py_round(impop_ctx *ctx, const double *x, uint64_t count, in
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(out, d_o, count * 8, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return IMPOP_OK;
+}
+
+IMPOP_API int impop_fst_grouped_from_identity(impop_ctx *ctx, const double *ident, uint32_t n, const uint8_t *in_a,
+                                              const uint8_t *in_b, double threshold, uint64_t seq_len, int round_digits,
+                                              double *out, uint64_t *counts) {
+    REQUIRE(ctx && out, "impop_fst_grouped_from_identity: NULL argument");
+    REQUIRE(n == 0 || (ident && in_a && in_b), "impop_fst_grouped_from_identity: NULL input");
+    REQUIRE(round_digits <= 19, "impop_fst_grouped_from_identity: round_digits > 19 unsupported");
+    HIP_TRY(hipSetDevice(ctx->device));
+    std::vector<uint32_t> ia, ib;
+    for (uint32_t i = 0; i < n; ++i) {  // members of both populations leave both (hud.py:186-190)
+        const bool ov = in_a[i] && in_b[i];
+        if (in_a[i] && !ov) ia.push_back(i);
+        if (in_b[i] && !ov) ib.push_back(i);
+    }
+    const uint32_t ma = (uint32_t)ia.size(), mb = (uint32_t)ib.size();
+    const size_t lds = (size_t)std::max(ma, mb) * 8 + ((size_t)ma + mb) * 8 + 16;
+    REQUIRE(lds <= 150 * 1024, "grouped Fst: populations too large for the LDS-resident grouping");
+    const size_t nn = (size_t)n * n;
+    void *d = nullptr;
+    int rc = ctx_scratch(ctx, carve_size({nn * 8, 8, sizeof(HfstOut), (size_t)ma * 4, (size_t)mb * 4}), &d);
+    if (rc) return rc;
+    Carve cv(d);
+    double *d_id = cv.take<double>(nn ? nn : 1);
+    uint64_t *d_L = cv.take<uint64_t>(1);
+    HfstOut *d_out = cv.take<HfstOut>(1);
+    uint32_t *d_ia = cv.take<uint32_t>(ma ? ma : 1), *d_ib = cv.take<uint32_t>(mb ? mb : 1);
+    if (nn) HIP_TRY(hipMemcpyAsync(d_id, ident, nn * 8, hipMemcpyHostToDevice, ctx->stream));
+    if (ma) HIP_TRY(hipMemcpyAsync(d_ia, ia.data(), (size_t)ma * 4, hipMemcpyHostToDevice, ctx->stream));
+    if (mb) HIP_TRY(hipMemcpyAsync(d_ib, ib.data(), (size_t)mb * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(d_L, &seq_len, 8, hipMemcpyHostToDevice, ctx->stream));
+    SimBatch b{};
+    b.dense = d_id; b.stride = nn; b.ld = n; b.n = n; b.round_digits = round_digits < 0 ? -1 : round_digits;
+    if (lds > 48 * 1024)
+        HIP_TRY(hipFuncSetAttribute((const void *)hud_grouped_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(hud_grouped_kernel, dim3(1), dim3(ST), lds, ctx->stream, b, d_ia, ma, d_ib, mb, threshold, d_L, d_out);
+    HIP_TRY(hipGetLastError());
+    HfstOut o;
+    HIP_TRY(hipMemcpyAsync(&o, d_out, sizeof o, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));  // ia / ib (pageable) must outlive the copies
+    for (int k = 0; k < 6; ++k) out[k] = o.v[k];
+    if (counts)
+        for (int k = 0; k < 6; ++k) counts[k] = o.cnt[k];
     return IMPOP_OK;
 }

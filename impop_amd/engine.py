@@ -195,6 +195,21 @@ class Context:
                                                 out.ctypes.data_as(C.POINTER(C.c_double)), cnt.ctypes.data_as(C.POINTER(C.c_uint64))))
         return out, cnt
 
+    def fst_grouped_from_identity(self, ident: np.ndarray, in_a, in_b, threshold: float, seq_len: Optional[int],
+                                  round_digits: Optional[int]):
+        a = np.ascontiguousarray(ident, dtype=np.float64)
+        n = a.shape[0] if a.ndim == 2 else 0
+        fa = np.ascontiguousarray(in_a, dtype=np.uint8)
+        fb = np.ascontiguousarray(in_b, dtype=np.uint8)
+        out = np.zeros(6)
+        cnt = np.zeros(6, dtype=np.uint64)
+        check(self._lib.impop_fst_grouped_from_identity(self.handle, a.ctypes.data_as(C.POINTER(C.c_double)), n,
+                                                        fa.ctypes.data_as(C.POINTER(C.c_uint8)), fb.ctypes.data_as(C.POINTER(C.c_uint8)),
+                                                        float(threshold), int(seq_len) if seq_len and seq_len > 0 else 0,
+                                                        -1 if round_digits is None else int(round_digits),
+                                                        out.ctypes.data_as(C.POINTER(C.c_double)), cnt.ctypes.data_as(C.POINTER(C.c_uint64))))
+        return out, cnt
+
     def tajimas_d(self, n, S, pi, components: bool = False):
         n_a = np.ascontiguousarray(np.atleast_1d(n), dtype=np.int64)
         S_a = np.ascontiguousarray(np.atleast_1d(S), dtype=np.float64)

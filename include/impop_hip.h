@@ -242,6 +242,14 @@ int impop_fst_from_identity(impop_ctx *ctx, const double *ident, uint32_t n, con
                             const uint8_t *in_b, uint64_t seq_len, int round_digits, double *out,
                             uint64_t *counts);
 
+/* scripts/hudson/hud.py calculate_fst(method='grouped') (hud.py:64-128, 173-300): greedy groups
+ * inside each population at `threshold`, frequency-weighted group-pair sums; the similarity of two
+ * groups is the first pair (members in sorted order) present in the table.  out[6] as above;
+ * counts[6] = groups_a, missing_a, groups_b, missing_b, group pairs between, missing between. */
+int impop_fst_grouped_from_identity(impop_ctx *ctx, const double *ident, uint32_t n, const uint8_t *in_a,
+                                    const uint8_t *in_b, double threshold, uint64_t seq_len, int round_digits,
+                                    double *out, uint64_t *counts);
+
 /* tj_d.tajimas_d (tj_d.py:47-69) for `count` (n, S, pi) triples.  comps
  * (nullable): count x 10 doubles a1,a2,b1,b2,c1,c2,e1,e2,numerator,denominator.
  * Returns IMPOP_E_INVALID (message = the reference's ValueError text) if any

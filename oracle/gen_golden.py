@@ -119,6 +119,7 @@ def main():
     hfst = load("ref_hfst", os.path.join(sc, "h-fst.py"))
     tjd = load("ref_tj_d", os.path.join(sc, "tj_d.py"))
     af = load("ref_af", os.path.join(sc, "af.py"))
+    hud = load("ref_hud", os.path.join(sc, "hudson", "hud.py"))
     os.makedirs(args.out, exist_ok=True)
     meta = {"python": sys.version.split()[0], "PYTHONHASHSEED": os.environ.get("PYTHONHASHSEED", "random"),
             "generator": "oracle/gen_golden.py", "reference": "pangenome/impop @ /root/reference (2025-10-31 snapshot)"}
@@ -259,6 +260,15 @@ def main():
             Bov = set(B) | set(list(A)[:2])
             r = hfst.calculate_fst(d, set(A), set(Bov), L, None)
             out["hfst_overlap"] = {"extra_in_b": sorted(list(A)[:2]), "L": L, "out": {k: hx(v) for k, v in r.items()}}
+            # hud.py grouped method: only where '> thr' is an equivalence relation inside BOTH populations
+            out["hud_grouped"] = []
+            for thr in (0.999, 0.99, float(np.median(offdiag)), 1.0):
+                for rd in (None, 4):
+                    ia, ib = [i for i in range(n) if inA[i]], [i for i in range(n) if inB[i]]
+                    if not (is_equivalence(sim[np.ix_(ia, ia)], thr, rd) and is_equivalence(sim[np.ix_(ib, ib)], thr, rd)):
+                        continue
+                    r = hud.calculate_fst(d, set(A), set(B), L, rd, None, "grouped", thr)
+                    out["hud_grouped"].append({"threshold": hx(thr), "round": rd, "L": L, "out": {k: hx(v) for k, v in r.items()}})
             rows = [(a.split(":", 1)[0], b.split(":", 1)[0], v) for (a, b), v in d.items()]
             samples = sorted({a for a, _, _ in rows} | {b for _, b, _ in rows})
             for thr in (1.0, 0.999, float(np.median(offdiag)), 0.0):

@@ -432,3 +432,92 @@ ORACLE_API int oracle_to_sitemajor(const uint64_t *bits, uint64_t stride, uint32
             if (bit_at(bits, stride, i, s)) sm[(size_t)s * wps64 + (i >> 6)] |= 1ull << (i & 63);
     return 0;
 }
+
+/* ------------------------------------------------------------------------- */
+/* scripts/hudson/hud.py "grouped" method (hud.py:64-128, 173-300).            */
+/* group_sequences (:64-86): pica2-style greedy groups INSIDE a population     */
+/* (seed = smallest remaining index here; the reference pops an arbitrary set  */
+/* member); get_group_similarity (:88-99): the first pair (member of g1 in     */
+/* sorted order x member of g2 in sorted order) present in the table.          */
+static uint32_t hud_groups(const double *sim, uint32_t n, const uint32_t *idx, uint32_t m, double thr, int rd, uint32_t *grp) {
+    const uint32_t NONE = 0xFFFFFFFFu;
+    for (uint32_t i = 0; i < m; ++i) grp[i] = NONE;
+    uint32_t G = 0;
+    for (uint32_t s = 0; s < m; ++s) {
+        if (grp[s] != NONE) continue;
+        grp[s] = G;
+        for (uint32_t o = s + 1; o < m; ++o) {
+            if (grp[o] != NONE) continue;
+            uint32_t a = idx[s], b = idx[o];
+            double v = a <= b ? sim[(size_t)a * n + b] : sim[(size_t)b * n + a];
+            if (isnan(v)) continue;                       /* :76 key in similarities */
+            if (rd >= 0) v = oracle_py_round(v, rd);      /* :78-79 */
+            if (v > thr) grp[o] = G;                      /* :80 */
+        }
+        ++G;
+    }
+    return G;
+}
+static double hud_first_found(const double *sim, uint32_t n, const uint32_t *ia, const uint32_t *ga, uint32_t ma, uint32_t g1,
+                              const uint32_t *ib, const uint32_t *gb, uint32_t mb, uint32_t g2, int rd) {
+    for (uint32_t i = 0; i < ma; ++i) { if (ga[i] != g1) continue;
+        for (uint32_t j = 0; j < mb; ++j) { if (gb[j] != g2) continue;
+            uint32_t a = ia[i], b = ib[j];
+            double v = a <= b ? sim[(size_t)a * n + b] : sim[(size_t)b * n + a];
+            if (isnan(v)) continue;
+            return rd >= 0 ? oracle_py_round(v, rd) : v;  /* :94-97 */
+        } }
+    return NAN;
+}
+static double hud_pi_grouped(const double *sim, uint32_t n, const uint32_t *idx, uint32_t m, double thr, int rd,
+                             uint32_t *grp, uint32_t *G_out, uint64_t *missing) {
+    uint32_t G = hud_groups(sim, n, idx, m, thr, rd, grp);
+    *G_out = G; *missing = 0;
+    if (m <= 1) return 0.0;                               /* :106-107 */
+    uint32_t *sz = (uint32_t *)calloc(G ? G : 1, sizeof(uint32_t));
+    for (uint32_t i = 0; i < m; ++i) sz[grp[i]]++;
+    double acc = 0.0;
+    for (uint32_t i = 0; i < G; ++i)
+        for (uint32_t j = i + 1; j < G; ++j) {            /* :114-115 */
+            double s = hud_first_found(sim, n, idx, grp, m, i, idx, grp, m, j, rd);
+            if (isnan(s)) { ++*missing; continue; }
+            double fi = (double)sz[i] / (double)m, fj = (double)sz[j] / (double)m;
+            acc += 2 * fi * fj * (1 - s);                 /* :121 */
+        }
+    free(sz);
+    return acc * (double)m / (double)(m - 1);             /* :127 */
+}
+/* out[6] = fst, pi_a, pi_b, pi_xy, dxy, da; counts[6] = groups_a, miss_a, groups_b, miss_b, group pairs, miss_between */
+ORACLE_API int oracle_hud_grouped(const double *sim, uint32_t n, const uint8_t *in_a, const uint8_t *in_b, double threshold,
+                                  int round_digits, double seq_len, double *out, uint64_t *counts) {
+    uint32_t *ia = (uint32_t *)malloc((n ? n : 1) * 4), *ib = (uint32_t *)malloc((n ? n : 1) * 4);
+    uint32_t *ga = (uint32_t *)malloc((n ? n : 1) * 4), *gb = (uint32_t *)malloc((n ? n : 1) * 4);
+    uint32_t ma = 0, mb = 0;
+    for (uint32_t i = 0; i < n; ++i) {                     /* overlap removed from both: hud.py:186-190 */
+        int ov = in_a[i] && in_b[i];
+        if (in_a[i] && !ov) ia[ma++] = i;
+        if (in_b[i] && !ov) ib[mb++] = i;
+    }
+    uint32_t GA, GB; uint64_t missA, missB, missX = 0, pairsX = 0;
+    double pi_a = hud_pi_grouped(sim, n, ia, ma, threshold, round_digits, ga, &GA, &missA);
+    double pi_b = hud_pi_grouped(sim, n, ib, mb, threshold, round_digits, gb, &GB, &missB);
+    double pi_xy = 0.5 * (pi_a + pi_b);
+    uint32_t *sa = (uint32_t *)calloc(GA ? GA : 1, 4), *sb = (uint32_t *)calloc(GB ? GB : 1, 4);
+    for (uint32_t i = 0; i < ma; ++i) sa[ga[i]]++;
+    for (uint32_t i = 0; i < mb; ++i) sb[gb[i]]++;
+    double dxy = 0.0;
+    for (uint32_t x = 0; x < GA; ++x)
+        for (uint32_t y = 0; y < GB; ++y) {                /* hud.py:247-259 */
+            double s = hud_first_found(sim, n, ia, ga, ma, x, ib, gb, mb, y, round_digits);
+            if (isnan(s)) { ++missX; continue; }
+            double w = ((double)sa[x] * (double)sb[y]) / ((double)ma * (double)mb);
+            dxy += w * (1 - s);
+            ++pairsX;
+        }
+    double fst = (dxy > 0) ? (dxy - pi_xy) / dxy : 0.0;
+    if (seq_len > 0) { out[0] = fst; out[1] = pi_a / seq_len; out[2] = pi_b / seq_len; out[3] = pi_xy / seq_len; out[4] = dxy / seq_len; out[5] = (dxy - pi_xy) / seq_len; }
+    else { out[0] = fst; out[1] = pi_a; out[2] = pi_b; out[3] = pi_xy; out[4] = dxy; out[5] = dxy - pi_xy; }
+    if (counts) { counts[0] = GA; counts[1] = missA; counts[2] = GB; counts[3] = missB; counts[4] = pairsX; counts[5] = missX; }
+    free(ia); free(ib); free(ga); free(gb); free(sa); free(sb);
+    return 0;
+}

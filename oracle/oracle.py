@@ -44,6 +44,7 @@ def lib():
         L.oracle_tajimas_d.argtypes = [C.c_int64, C.c_double, C.c_double, _f64p, _f64p]
         L.oracle_pica2.argtypes = [_f64p, C.c_uint32, C.c_double, C.c_int, C.c_double, _f64p, _f64p, _u32p, _u32p]
         L.oracle_hfst.argtypes = [_f64p, C.c_uint32, _u8p, _u8p, C.c_double, C.c_int, _f64p, _u64p]
+        L.oracle_hud_grouped.argtypes = [_f64p, C.c_uint32, _u8p, _u8p, C.c_double, C.c_int, C.c_double, _f64p, _u64p]
         L.oracle_af_cluster.argtypes = [_f64p, C.c_uint32, C.c_double, _u32p, _u32p, _u32p]
         L.oracle_pairwise_counts.argtypes = [_u64p, C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint64, _i64p]
         L.oracle_identity.argtypes = [_i64p, C.c_uint32, C.c_uint64, C.c_int, _f64p]
@@ -101,6 +102,19 @@ def hfst(sim, in_a, in_b, seq_len=None, round_digits=None):
     cnt = np.zeros(6, dtype=np.uint64)
     lib().oracle_hfst(_p(a, _f64p), n, _p(fa, _u8p), _p(fb, _u8p), float(seq_len or 0),
                       -1 if round_digits is None else int(round_digits), _p(out, _f64p), _p(cnt, _u64p))
+    keys = ("fst", "pi_a", "pi_b", "pi_xy", "dxy", "da")
+    return dict(zip(keys, out.tolist())), cnt
+
+
+def hud_grouped(sim, in_a, in_b, threshold=0.999, seq_len=None, round_digits=None):
+    a = _dense(sim)
+    n = a.shape[0]
+    fa = np.ascontiguousarray(in_a, dtype=np.uint8)
+    fb = np.ascontiguousarray(in_b, dtype=np.uint8)
+    out = np.zeros(6)
+    cnt = np.zeros(6, dtype=np.uint64)
+    lib().oracle_hud_grouped(_p(a, _f64p), n, _p(fa, _u8p), _p(fb, _u8p), float(threshold),
+                             -1 if round_digits is None else int(round_digits), float(seq_len or 0), _p(out, _f64p), _p(cnt, _u64p))
     keys = ("fst", "pi_a", "pi_b", "pi_xy", "dxy", "da")
     return dict(zip(keys, out.tolist())), cnt
 

@@ -496,3 +496,33 @@ def test_fuzz_scan_and_gram_random_shapes(ctx, oracle):
             I = bm.pairwise_counts(s0, s1)
             assert (I.astype(np.int64) == oracle.pairwise_counts(bits, n, s0, s1)).all(), ("gram", it, n, W, s0, s1)
         bm.free()
+
+
+def test_hud_grouped_fst_vs_reference_goldens(ctx, oracle):
+    """scripts/hudson/hud.py method='grouped' (goldens captured from the real hud.py) through the
+    reference-API mirror impop_amd.hud.calculate_fst, plus the oracle on a non-golden threshold."""
+    from impop_amd import hud
+    g = load_golden("bitmatrix.json")
+    for mrec in g["matrices"]:
+        n, W = mrec["n"], mrec["W"]
+        nm = mrec["names"]
+        inA, inB = np.array(mrec["in_a"], np.uint8), np.array(mrec["in_b"], np.uint8)
+        A = {nm[i] for i in range(n) if inA[i]}
+        B = {nm[i] for i in range(n) if inB[i]}
+        for kind, kid in (("match", 0), ("dice", 1)):
+            sim = oracle.identity(golden_counts(mrec), W, kid)
+            d = {(nm[i], nm[j]): float(sim[i, j]) for i in range(n) for j in range(i, n)}
+            for c in mrec["kinds"][kind]["hud_grouped"]:
+                r = hud.calculate_fst(d, set(A), set(B), c["L"], c["round"], None, "grouped", fh(c["threshold"]), ctx=ctx)
+                for k, v in c["out"].items():
+                    assert rel_close(r[k], fh(v), REL, 1e-300), (mrec["name"], kind, k, c)
+            out, cnt = ctx.fst_grouped_from_identity(sim, inA, inB, 0.9975, 777, 3)
+            want, wcnt = oracle.hud_grouped(sim, inA, inB, 0.9975, 777, 3)
+            for k, key in enumerate(("fst", "pi_a", "pi_b", "pi_xy", "dxy", "da")):
+                assert rel_close(float(out[k]), want[key], REL, 1e-300), (mrec["name"], kind, key)
+            assert (cnt == wcnt).all()
+        # method='direct' is h-fst
+        r = hud.calculate_fst(d, set(A), set(B), mrec["L"], None, None, "direct", ctx=ctx)
+        ref_h = [c for c in mrec["kinds"]["dice"]["hfst"] if c["L"] == mrec["L"] and c["round"] is None][0]["out"]
+        for k, v in ref_h.items():
+            assert rel_close(r[k], fh(v), REL, 1e-300)

@@ -116,6 +116,10 @@ def test_bitmatrix_goldens(oracle):
             r, _ = oracle.hfst(sim, inA, inB2, ov["L"], None)
             for k, v in ov["out"].items():
                 assert rel_close(r[k], fh(v), TOL, 1e-18)
+            for c in out["hud_grouped"]:
+                r, _ = oracle.hud_grouped(sim, inA, inB, fh(c["threshold"]), c["L"], c["round"])
+                for k, v in c["out"].items():
+                    assert rel_close(r[k], fh(v), TOL, 1e-18), (m["name"], kind, "hud", k, c)
             trunc = [s.split(":", 1)[0] for s in m["names"]]
             for c in out["af"]:
                 cl, K, sz = oracle.af_cluster(sim, fh(c["threshold"]))

@@ -319,6 +319,23 @@ def main():
         bad2 = os.path.join(td, "bad2.sim")
         open(bad2, "w").write("group.a\tgroup.b\testimated.identity\nx\ty\tzzz\n")
         cli["errors"].append(run2([os.path.join(sc, "pica2.py"), bad2, "-d", td]))
+        # scripts/hudson/hud.py CLI (exact-name populations): direct + grouped; log file captured too
+        ha, hb = os.path.join(td, "hudA.txt"), os.path.join(td, "hudB.txt")
+        open(ha, "w").write("# A\n" + "\n".join(m8["names"][:4]) + "\nNOPE#1#x:0-1\n")
+        open(hb, "w").write("\n".join(m8["names"][3:8]) + "\n")
+        hud_py = os.path.join(sc, "hudson", "hud.py")
+        def run_hud(extra):
+            r = run2([hud_py, p, "-a", ha, "-b", hb, "-d", td] + extra)
+            r["log"] = open(os.path.join(td, "win8_fst.log")).read()
+            return r
+        cli["hudA"], cli["hudB"] = open(ha).read(), open(hb).read()
+        hud_runs = [run_hud(["-l", "1000"]), run_hud(["-m", "direct", "-r", "3", "-v"]), run_hud(["-m", "grouped", "-t", "1.0", "-l", "1000"])]
+        for t, r in (("0.999", "5"), ("0.99", None), ("0.995", None)):
+            subA = [i for i in range(0, 3)]; subB = [i for i in range(4, 8)]  # index 3 is in both -> dropped
+            ok = all(is_equivalence(sim8[np.ix_(sub, sub)], float(t), int(r) if r else None) for sub in (subA, subB))
+            if ok:
+                hud_runs.append(run_hud(["-m", "grouped", "-t", t] + (["-r", r] if r else []) + ["-v"]))
+        cli["hud"] = hud_runs
         # is pica2 @ t=0.999 -r 5 order-independent on this table?
         cli["pica2_equivalence"] = [is_equivalence(sim8, 1.0, None), is_equivalence(sim8, 0.999, 5), is_equivalence(sim8, 0.99, None)]
     json.dump({"meta": meta, **cli}, open(os.path.join(args.out, "cli_pansn.json"), "w"), indent=1)

@@ -82,6 +82,15 @@ def test_pansn_cli(tmp_path):
             assert r.returncode == c["rc"], (script, c["argv"], r.stderr)
             assert r.stdout == c["stdout"], (script, c["argv"], r.stdout, c["stdout"])
             assert r.stderr == c["stderr"], (script, c["argv"], r.stderr, c["stderr"])
+    # scripts/hudson/hud.py: direct + grouped, stdout / stderr / the log file text
+    open(os.path.join(td, "hudA.txt"), "w").write(g["hudA"])
+    open(os.path.join(td, "hudB.txt"), "w").write(g["hudB"])
+    for c in g["hud"]:
+        r = run("hud.py", remap(c["argv"], td), td)
+        assert r.returncode == c["rc"], (c["argv"], r.stderr)
+        assert r.stdout == c["stdout"], (c["argv"], r.stdout, c["stdout"])
+        assert r.stderr.replace(td, "<TMP>") == c["stderr"], (c["argv"], r.stderr, c["stderr"])
+        assert open(os.path.join(td, "win8_fst.log")).read() == c["log"], c["argv"]
     for c in g["errors"]:
         script = c["argv"][0]
         r = run(script, remap(c["argv"], td), td)

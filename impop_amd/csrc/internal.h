@@ -48,6 +48,15 @@ struct SbGeom {
     uint64_t n_block = 0;  // ceil(n_site/64)
 };
 
+// dword index of (block b, lane/site l, dword k) in the SB64 layout
+__host__ __device__ inline uint64_t sb_index(uint32_t wps, uint32_t G, uint32_t r, uint64_t b, uint32_t l,
+                                             uint32_t k) {
+    const uint32_t g = k >> 2;
+    const uint64_t base = b * 64ull * wps;
+    return (g + 1 < G) ? base + (uint64_t)g * 256 + l * 4 + (k & 3)
+                       : base + (uint64_t)(G - 1) * 256 + (uint64_t)l * r + (k - 4 * (G - 1));
+}
+
 }  // namespace impop
 
 struct impop_ctx {

@@ -11,14 +11,6 @@
 
 namespace impop {
 
-__host__ __device__ inline uint64_t sb_index(uint32_t wps, uint32_t G, uint32_t r, uint64_t b, uint32_t l,
-                                             uint32_t k) {
-    const uint32_t g = k >> 2;
-    const uint64_t base = b * 64ull * wps;
-    return (g + 1 < G) ? base + (uint64_t)g * 256 + l * 4 + (k & 3)
-                       : base + (uint64_t)(G - 1) * 256 + (uint64_t)l * r + (k - 4 * (G - 1));
-}
-
 static SbGeom make_geom(uint32_t n_hap, uint64_t n_site) {
     SbGeom g;
     g.n_hap = n_hap;

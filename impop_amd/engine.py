@@ -321,6 +321,14 @@ class BitMatrix:
                                               out.ctypes.data_as(C.POINTER(C.c_uint32))))
         return out
 
+    def ehh(self, site_begin: int, site_end: int, mask=None, reverse: bool = False) -> np.ndarray:
+        """calc_EHH (scripts/wip/ehhgfa.py:6-21) of the members of `mask` over [site_begin, site_end)."""
+        out = np.zeros(max(site_end - site_begin, 0))
+        keep, ptr = _mask_ptr(mask, self.n_hap)
+        check(self.ctx._lib.impop_ehh(self.ctx.handle, self.handle, int(site_begin), int(site_end), ptr, 1 if reverse else 0,
+                                      out.ctypes.data_as(C.POINTER(C.c_double)), None))
+        return out
+
     def pairwise_counts(self, site_begin: int, site_end: int) -> np.ndarray:
         out = np.zeros((self.n_hap, self.n_hap), dtype=np.int32)
         check(self.ctx._lib.impop_pairwise_counts(self.ctx.handle, self.handle, int(site_begin), int(site_end),

@@ -187,6 +187,14 @@ int impop_afs(impop_ctx *ctx, const impop_matrix *m, const impop_window *windows
 int impop_site_counts(impop_ctx *ctx, const impop_matrix *m, const uint64_t *mask, uint64_t site_begin,
                       uint64_t site_end, uint32_t *counts_out_host);
 
+/* Extended haplotype homozygosity, calc_EHH of scripts/wip/ehhgfa.py:6-21: out[i] =
+ * round(#{pairs of `mask` members (NULL = all) identical on window sites 0..i} / (m(m-1)/2), 3),
+ * i over [site_begin, site_end).  reverse != 0 walks the window from its last site backwards
+ * (calc_EHH of the column-flipped matrix, ehhgfa.py:61).  m < 2 fills 500.0 (ehhgfa.py:17-18).
+ * n_members (nullable) receives m. */
+int impop_ehh(impop_ctx *ctx, const impop_matrix *m, uint64_t site_begin, uint64_t site_end, const uint64_t *mask,
+              int reverse, double *ehh_out_host, uint32_t *n_members);
+
 /* ---- all-pairs path -------------------------------------------------------
  * I_ij = #sites of the window carried by both i and j (the quantity behind
  * `impg similarity`'s estimated.identity, run_pica2_impg.sh:162); a_i = I_ii.

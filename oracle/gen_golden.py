@@ -340,6 +340,35 @@ def main():
         cli["pica2_equivalence"] = [is_equivalence(sim8, 1.0, None), is_equivalence(sim8, 0.999, 5), is_equivalence(sim8, 0.99, None)]
     json.dump({"meta": meta, **cli}, open(os.path.join(args.out, "cli_pansn.json"), "w"), indent=1)
 
+    # ---------------------------------------------- EHH (scripts/wip/ehhgfa.py calc_EHH + CLI)
+    ehh_mod = load("ref_ehhgfa", os.path.join(sc, "wip", "ehhgfa.py"))
+    rng = np.random.default_rng(20251101)
+    ehh = {"meta": meta, "calc": [], "cli": []}
+    for n, W, nf, pf, pp in ((1, 5, 1, 0.0, 0.0), (2, 9, 2, 0.2, 0.0), (5, 19, 2, 0.15, 0.02), (8, 40, 3, 0.08, 0.01),
+                             (12, 130, 3, 0.03, 0.004), (7, 64, 2, 0.05, 0.0), (9, 65, 3, 0.02, 0.003), (6, 1, 2, 0.5, 0.0)):
+        h = founder_matrix(rng, n, W, nf, pf, pp)[0].astype(np.int64)
+        ehh["calc"].append({"n": n, "W": W, "rows": ["".join(map(str, r)) for r in h.tolist()],
+                            "fwd": [hx(float(v)) for v in ehh_mod.calc_EHH(h)],
+                            "rev": [hx(float(v)) for v in ehh_mod.calc_EHH(np.flip(h, axis=1))]})
+    hv = rng.integers(0, 10, size=(6, 14))  # value matrix in the style of ehh2.py's digit examples
+    hv[1] = hv[0]; hv[2, :9] = hv[0, :9]; hv[4, :5] = hv[3, :5]
+    ehh["values"] = {"rows": hv.tolist(), "fwd": [hx(float(v)) for v in ehh_mod.calc_EHH(hv)],
+                     "rev": [hx(float(v)) for v in ehh_mod.calc_EHH(np.flip(hv, axis=1))]}
+    with tempfile.TemporaryDirectory() as td:
+        for n, Wt, w, ptest, refpos in ((10, 60, 20, 5, 1), (8, 48, 16, 1, 3), (9, 50, 20, 8, 2), (6, 30, 10, 10, 1)):
+            h = founder_matrix(rng, n, Wt, 3, 0.06, 0.01)[0].astype(np.int64)
+            h[h[:, 0] == 1, 3] = 7  # a non 0/1 entry: ehhgfa.py:50 maps non-zero to 1
+            f, o = os.path.join(td, "hap.txt"), os.path.join(td, "out.txt")
+            np.savetxt(f, h, fmt="%d")
+            if os.path.exists(o):
+                os.remove(o)
+            r = subprocess.run([sys.executable, "-B", os.path.join(sc, "wip", "ehhgfa.py"), "-i", f, "-p", str(ptest), "-w", str(w),
+                                "-refpos", str(refpos), "-o", o], capture_output=True, text=True, cwd=td)
+            ehh["cli"].append({"matrix_text": open(f).read(), "p": ptest, "w": w, "refpos": refpos, "rc": r.returncode,
+                               "out": open(o).read() if os.path.exists(o) else None,
+                               "stderr_last": r.stderr.strip().splitlines()[-1] if r.stderr.strip() else ""})
+    json.dump(ehh, open(os.path.join(args.out, "ehh.json"), "w"), indent=1)
+
     # ---------------------------------------------- missing pairs / ragged .sim
     n = 7
     names = names_for(n)

@@ -521,3 +521,41 @@ ORACLE_API int oracle_hud_grouped(const double *sim, uint32_t n, const uint8_t *
     free(ia); free(ib); free(ga); free(gb); free(sa); free(sb);
     return 0;
 }
+
+/* ---- EHH: calc_EHH of scripts/wip/ehhgfa.py:6-21 (and ehh2.py:76-89) ----------------------------
+ * Literal restatement on the packed matrix: for every prefix length i+1 count the pairs of member
+ * rows that are equal on all of window sites 0..i (kept incrementally in `alive`: a pair that
+ * differed once never matches a longer prefix), divide by m(m-1)/2, CPython round(, 3).
+ * reverse != 0 = calc_EHH of the column-flipped window (ehhgfa.py:60-61).  m < 2 -> 500. */
+ORACLE_API void oracle_ehh(const uint64_t *bits, uint64_t words, uint32_t n, uint64_t s0, uint64_t s1, const uint8_t *member,
+                int reverse, double *out) {
+    uint32_t *idx = (uint32_t *)malloc(sizeof(uint32_t) * (n ? n : 1));
+    uint32_t m = 0;
+    for (uint32_t i = 0; i < n; ++i)
+        if (!member || member[i]) idx[m++] = i;
+    const uint64_t W = s1 - s0;
+    if (m < 2) {
+        for (uint64_t i = 0; i < W; ++i) out[i] = 500.0;
+        free(idx);
+        return;
+    }
+    const uint64_t n_pairs = (uint64_t)m * (m - 1) / 2;
+    uint8_t *alive = (uint8_t *)malloc(n_pairs);
+    memset(alive, 1, n_pairs);
+    const double denom = (double)((uint64_t)m * (m - 1)) / 2.0;
+    for (uint64_t i = 0; i < W; ++i) {
+        const uint64_t s = reverse ? s1 - 1 - i : s0 + i;
+        uint64_t homozygous = 0, p = 0;
+        for (uint32_t j = 0; j < m; ++j) {
+            const uint64_t bj = (bits[(uint64_t)idx[j] * words + (s >> 6)] >> (s & 63)) & 1u;
+            for (uint32_t k = j + 1; k < m; ++k, ++p) {
+                const uint64_t bk = (bits[(uint64_t)idx[k] * words + (s >> 6)] >> (s & 63)) & 1u;
+                if (bj != bk) alive[p] = 0;
+                homozygous += alive[p];
+            }
+        }
+        out[i] = oracle_py_round((double)homozygous / denom, 3);
+    }
+    free(alive);
+    free(idx);
+}

@@ -45,6 +45,7 @@ def lib():
         L.oracle_pica2.argtypes = [_f64p, C.c_uint32, C.c_double, C.c_int, C.c_double, _f64p, _f64p, _u32p, _u32p]
         L.oracle_hfst.argtypes = [_f64p, C.c_uint32, _u8p, _u8p, C.c_double, C.c_int, _f64p, _u64p]
         L.oracle_hud_grouped.argtypes = [_f64p, C.c_uint32, _u8p, _u8p, C.c_double, C.c_int, C.c_double, _f64p, _u64p]
+        L.oracle_ehh.argtypes = [_u64p, C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint64, _u8p, C.c_int, _f64p]
         L.oracle_af_cluster.argtypes = [_f64p, C.c_uint32, C.c_double, _u32p, _u32p, _u32p]
         L.oracle_pairwise_counts.argtypes = [_u64p, C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint64, _i64p]
         L.oracle_identity.argtypes = [_i64p, C.c_uint32, C.c_uint64, C.c_int, _f64p]
@@ -191,6 +192,15 @@ def window_allpairs(bits, n, s0, s1, mp, ma, mb, seq_len, d_pi_mode=0, s_scope=0
 
 def window_sitecount(bits, n, s0, s1, mp, ma, mb, seq_len, d_pi_mode=0, s_scope=0):
     return _window(lib().oracle_window_sitecount, bits, n, s0, s1, mp, ma, mb, seq_len, d_pi_mode, s_scope)
+
+
+def ehh(bits, n, s0, s1, member=None, reverse=False):
+    b = np.ascontiguousarray(bits, dtype=np.uint64)
+    out = np.zeros(max(int(s1) - int(s0), 0))
+    mem = None if member is None else np.ascontiguousarray(member, dtype=np.uint8)
+    lib().oracle_ehh(_p(b, _u64p), b.shape[1], n, int(s0), int(s1), None if mem is None else _p(mem, _u8p),
+                     1 if reverse else 0, _p(out, _f64p))
+    return out
 
 
 def to_sitemajor(bits, n, n_site):

@@ -104,3 +104,18 @@ def test_pansn_cli(tmp_path):
             assert r.stdout == want_out
         assert norm(r.stderr) == c["stderr"]
     assert os.path.exists(os.path.join(td, "win8.log")) and os.path.exists(os.path.join(td, "win8_fst.log"))
+
+
+def test_ehhgfa_cli(tmp_path):
+    """scripts/ehhgfa.py writes the rows the reference's scripts/wip/ehhgfa.py wrote for the same
+    matrix file (goldens captured by oracle/gen_golden.py), incl. the crash on an empty half."""
+    g = load_golden("ehh.json")
+    td = str(tmp_path)
+    for k, c in enumerate(g["cli"]):
+        f, o = os.path.join(td, f"hap{k}.txt"), os.path.join(td, f"out{k}.txt")
+        open(f, "w").write(c["matrix_text"])
+        r = run("ehhgfa.py", ["-i", f, "-p", str(c["p"]), "-w", str(c["w"]), "-refpos", str(c["refpos"]), "-o", o], td)
+        assert r.returncode == c["rc"], (c["p"], c["w"], r.stderr)
+        assert open(o).read() == c["out"], (c["p"], c["w"])
+        if c["rc"]:
+            assert r.stderr.strip().splitlines()[-1] == c["stderr_last"]

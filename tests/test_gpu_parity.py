@@ -526,3 +526,40 @@ def test_hud_grouped_fst_vs_reference_goldens(ctx, oracle):
         ref_h = [c for c in mrec["kinds"]["dice"]["hfst"] if c["L"] == mrec["L"] and c["round"] is None][0]["out"]
         for k, v in ref_h.items():
             assert rel_close(r[k], fh(v), REL, 1e-300)
+
+
+def test_ehh_vs_reference_goldens_and_oracle(ctx, oracle):
+    """impop_ehh (scripts/wip/ehhgfa.py calc_EHH): bit-for-bit the goldens captured from the real
+    reference; the oracle on larger windows with unaligned edges, subsets and both directions."""
+    from impop_amd import ehh as ehh_mod
+    g = load_golden("ehh.json")
+    for c in g["calc"]:
+        m01 = np.array([[int(ch) for ch in r] for r in c["rows"]], dtype=np.uint8)
+        got = ehh_mod.calc_EHH(m01, ctx=ctx)
+        assert got.tolist() == [fh(v) for v in c["fwd"]], (m01.shape,)
+        assert ehh_mod.calc_EHH(np.flip(m01, axis=1), ctx=ctx).tolist() == [fh(v) for v in c["rev"]]
+        if m01.shape[0] >= 2:
+            bm = ctx.upload_dense(m01, keep_hap_major=False)
+            assert bm.ehh(0, m01.shape[1], reverse=True).tolist() == [fh(v) for v in c["rev"]]
+            bm.free()
+    hv = np.array(g["values"]["rows"])
+    assert ehh_mod.calc_EHH(hv, ctx=ctx).tolist() == [fh(v) for v in g["values"]["fwd"]]
+    assert ehh_mod.calc_EHH(np.flip(hv, axis=1), ctx=ctx).tolist() == [fh(v) for v in g["values"]["rev"]]
+
+    rng = np.random.default_rng(77)
+    n, W = 70, 3000
+    anc = rng.integers(0, 2, size=W, dtype=np.uint8)
+    f = np.repeat(anc[None, :], 4, axis=0) ^ (rng.random((4, W)) < 0.004).astype(np.uint8)
+    m01 = f[rng.integers(0, 4, size=n)] ^ (rng.random((n, W)) < 0.0005).astype(np.uint8)
+    bits = oracle.pack_hap_major(m01)
+    bm = ctx.upload_dense(m01, keep_hap_major=False)
+    member = (rng.random(n) < 0.6).astype(np.uint8)
+    for s0, s1 in ((0, W), (5, 1999), (64, 128), (63, 65), (130, 131), (1000, 1000), (777, 2999)):
+        for mem in (None, member):
+            for rev in (False, True):
+                got = bm.ehh(s0, s1, mem, reverse=rev)
+                want = oracle.ehh(bits, n, s0, s1, mem, rev)
+                assert got.tolist() == want.tolist(), (s0, s1, mem is not None, rev)
+    one = np.zeros(n, np.uint8); one[3] = 1
+    assert bm.ehh(10, 20, one).tolist() == [500.0] * 10
+    bm.free()

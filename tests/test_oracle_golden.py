@@ -181,3 +181,24 @@ def test_ref_style_python_chain_matches_oracle(oracle):
     for k in ("pi", "pi_site", "pi_a", "pi_b", "pi_xy", "dxy", "da", "fst", "tajima_d"):
         assert rel_close(got[k], want[k], 1e-12, 1e-18), (k, got[k], want[k])
     assert rel_close(got["tajima_d"], fh(m["tajd_chain"]["D"]), 1e-12)
+
+
+def test_ehh_oracle_matches_reference_goldens(oracle):
+    """oracle_ehh == calc_EHH of the real scripts/wip/ehhgfa.py (forward and column-flipped),
+    incl. the m < 2 -> 500 rule and a value (non 0/1) matrix through the bit-plane expansion."""
+    o = oracle
+    g = load_golden("ehh.json")
+    for c in g["calc"]:
+        m01 = np.array([[int(ch) for ch in r] for r in c["rows"]], dtype=np.uint8)
+        bits = o.pack_hap_major(m01)
+        n, W = m01.shape
+        assert o.ehh(bits, n, 0, W).tolist() == [fh(v) for v in c["fwd"]], (n, W)
+        assert o.ehh(bits, n, 0, W, reverse=True).tolist() == [fh(v) for v in c["rev"]], (n, W)
+    from impop_amd.ehh import _bit_planes
+    hv = np.array(g["values"]["rows"])
+    planes, last = _bit_planes(hv)
+    got = o.ehh(o.pack_hap_major(planes), hv.shape[0], 0, planes.shape[1])[last]
+    assert got.tolist() == [fh(v) for v in g["values"]["fwd"]]
+    planes_r, last_r = _bit_planes(np.flip(hv, axis=1))
+    got_r = o.ehh(o.pack_hap_major(planes_r), hv.shape[0], 0, planes_r.shape[1])[last_r]
+    assert got_r.tolist() == [fh(v) for v in g["values"]["rev"]]

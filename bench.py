@@ -89,6 +89,26 @@ def cpu_baseline(bm, windows, in_a, in_b, budget_s=12.0):
         t_sc += time.perf_counter() - t0
         n_sc += 1
         j += 1
+    # the same port on every host core (OpenMP over windows) on a 64-window slab, repeated for ~3 s
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    Wn = int(windows[0]["site_end"]) - int(windows[0]["site_begin"])
+    n_slab = min(64, len(windows))
+    uniform = all(int(w["site_end"]) - int(w["site_begin"]) == Wn and int(w["site_begin"]) == k * Wn
+                  for k, w in enumerate(windows[:n_slab]))
+    mt = None
+    if uniform and n_slab:
+        sm = orc.to_sitemajor(bm.download(0, n_slab * Wn), n, n_slab * Wn)
+        ints1, sums1 = orc.site_scan_sitemajor_windows(sm, n, Wn, n_slab, ones, ma, mb, 1)
+        t_mt, reps = 0.0, 0
+        while t_mt < 3.0:
+            t0 = time.perf_counter()
+            ints_m, sums_m = orc.site_scan_sitemajor_windows(sm, n, Wn, n_slab, ones, ma, mb, cores)
+            t_mt += time.perf_counter() - t0
+            reps += 1
+        assert (ints_m == ints1).all() and (sums_m == sums1).all()
+        mt = {"value": reps * n_slab / t_mt, "unit": "windows/s", "cores": cores,
+              "sample": f"{n_slab}-window slab x {reps} passes, OpenMP over windows, {t_mt:.1f} s"}
+        del sm
     # reference-STYLE chain (TSV text -> csv.DictReader -> dict algorithms), pure Python, 2 windows
     from oracle import ref_style
     t_py, n_py, py_rec = 0.0, 0, None
@@ -112,6 +132,7 @@ def cpu_baseline(bm, windows, in_a, in_b, budget_s=12.0):
                   f"(all-pairs Hamming + pica2/h-fst/tj_d restatement, gcc -O2, 1 thread, {t_all:.1f} s)",
         "sitecount_port": {"value": n_sc / t_sc if t_sc > 0 else None, "unit": "windows/s", "cores": 1,
                            "sample": f"{n_sc} windows, oracle_site_scan_sitemajor (integer sums only), {t_sc:.1f} s"},
+        "sitecount_port_allcores": mt,
         "reference_python_measured_in_build_container": "0.67-0.91 s/window for pica2.py alone (BASELINE.md §2)",
     }, first
 
@@ -152,8 +173,12 @@ def main():
         local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # IMPOP_BENCH_FORCE_DIST=1: build the process group even for one rank, so that the RCCL
+    # communicator + all_gather_into_tensor path can be exercised on a one-GPU box
+    use_dist = world > 1 or os.environ.get("IMPOP_BENCH_FORCE_DIST") == "1"
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
@@ -177,7 +202,7 @@ def main():
     # (compute stream); a buffer is rewritten only after its previous gather has been waited for
     bufs = [torch.empty(NW * 128, dtype=torch.uint8, device=dev) for _ in range(2)]
     gdev = dev if backend == "nccl" else torch.device("cpu")
-    gathered = [torch.empty(world * NW * 128, dtype=torch.uint8, device=gdev) for _ in range(2)] if world > 1 else None
+    gathered = [torch.empty(world * NW * 128, dtype=torch.uint8, device=gdev) for _ in range(2)] if use_dist else None
     works = [None, None]
     counter = [0]
 
@@ -187,7 +212,7 @@ def main():
         if works[b] is not None:
             works[b].wait()
         plan.launch(bufs[b].data_ptr())
-        if world > 1:
+        if use_dist:
             works[b] = dist.all_gather_into_tensor(gathered[b], bufs[b] if backend == "nccl" else bufs[b].cpu(), async_op=True)
 
     def drain():
@@ -201,7 +226,7 @@ def main():
     step()
     drain()
     recs = np.frombuffer(bufs[0].cpu().numpy().tobytes(), dtype=impop_amd.STATS_DTYPE)
-    if world > 1:  # every rank must hold every rank's records after the gather
+    if use_dist:  # every rank must hold every rank's records after the gather
         allrec = np.frombuffer(gathered[0].cpu().numpy().tobytes(), dtype=impop_amd.STATS_DTYPE)
         assert allrec[rank * NW: (rank + 1) * NW].tobytes() == recs.tobytes()
     cpu, first = None, None
@@ -226,20 +251,20 @@ def main():
         step()
     drain()
     plan.timing(True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     drain()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize(dev)
     elapsed = time.perf_counter() - t0
     kern_ms, launches = plan.elapsed()
     plan.timing(False)
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=gdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -278,7 +303,7 @@ def main():
     plan.destroy()
     bm.free()
     ctx.close()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

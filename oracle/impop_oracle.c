@@ -424,6 +424,19 @@ ORACLE_API int oracle_site_scan_sitemajor(const uint64_t *sm, uint32_t wps64, ui
     return 0;
 }
 
+/* All-core form of the timing port: consecutive windows of `window_sites` sites over one
+ * site-major slab, OpenMP over windows (bench.py cpu_baseline "sitecount_port_allcores"). */
+ORACLE_API int oracle_site_scan_sitemajor_windows(const uint64_t *sm, uint32_t wps64, uint32_t n, uint64_t window_sites,
+                                                  uint64_t n_win, const uint64_t *mp, const uint64_t *ma, const uint64_t *mb,
+                                                  int threads, uint32_t *ints, uint64_t *sums) {
+    if (threads < 1) threads = 1;
+#pragma omp parallel for num_threads(threads) schedule(static)
+    for (int64_t w = 0; w < (int64_t)n_win; ++w)
+        oracle_site_scan_sitemajor(sm, wps64, n, (uint64_t)w * window_sites, (uint64_t)(w + 1) * window_sites, mp, ma, mb,
+                                   ints + 8 * w, sums + 4 * w);
+    return 0;
+}
+
 /* hap-major -> site-major (64-bit words per site) helper for the timing port. */
 ORACLE_API int oracle_to_sitemajor(const uint64_t *bits, uint64_t stride, uint32_t n, uint64_t n_site, uint64_t *sm, uint32_t wps64) {
     memset(sm, 0, (size_t)n_site * wps64 * sizeof(uint64_t));

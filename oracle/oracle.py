@@ -55,6 +55,8 @@ def lib():
                           C.c_double, C.c_int, C.c_int, _u32p, _u64p, _f64p]
         L.oracle_site_scan_sitemajor.argtypes = [_u64p, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint64,
                                                  _u64p, _u64p, _u64p, _u32p, _u64p]
+        L.oracle_site_scan_sitemajor_windows.argtypes = [_u64p, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint64,
+                                                         _u64p, _u64p, _u64p, C.c_int, _u32p, _u64p]
         L.oracle_to_sitemajor.argtypes = [_u64p, C.c_uint64, C.c_uint32, C.c_uint64, _u64p, C.c_uint32]
         _lib = L
     return _lib
@@ -217,4 +219,13 @@ def site_scan_sitemajor(sm, n, s0, s1, mp, ma, mb):
     mp, ma, mb = (np.ascontiguousarray(m, dtype=np.uint64) for m in (mp, ma, mb))
     lib().oracle_site_scan_sitemajor(_p(sm, _u64p), sm.shape[1], n, int(s0), int(s1), _p(mp, _u64p),
                                      _p(ma, _u64p), _p(mb, _u64p), _p(ints, _u32p), _p(sums, _u64p))
+    return ints, sums
+
+
+def site_scan_sitemajor_windows(sm, n, window_sites, n_win, mp, ma, mb, threads):
+    ints = np.zeros((n_win, 8), dtype=np.uint32)
+    sums = np.zeros((n_win, 4), dtype=np.uint64)
+    mp, ma, mb = (np.ascontiguousarray(m, dtype=np.uint64) for m in (mp, ma, mb))
+    lib().oracle_site_scan_sitemajor_windows(_p(sm, _u64p), sm.shape[1], n, int(window_sites), int(n_win), _p(mp, _u64p),
+                                             _p(ma, _u64p), _p(mb, _u64p), int(threads), _p(ints, _u32p), _p(sums, _u64p))
     return ints, sums

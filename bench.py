@@ -51,6 +51,21 @@ def pmc_traffic(n_hap, window, n_windows):
     return None, None
 
 
+def host_cores():
+    """Threads for the all-core CPU port: the affinity mask, clipped by the cgroup CPU quota and by the
+    16-core share a one-GPU box of this pool grants (IMPOP_BENCH_CPU_THREADS overrides)."""
+    if os.environ.get("IMPOP_BENCH_CPU_THREADS"):
+        return max(int(os.environ["IMPOP_BENCH_CPU_THREADS"]), 1)
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(int(int(quota) / int(period) + 0.999), 1))
+    except (OSError, ValueError):
+        pass
+    return max(min(n, 16), 1)
+
+
 def cpu_baseline(bm, windows, in_a, in_b, budget_s=12.0):
     """Time the CPU oracle (oracle/impop_oracle.c, the restated reference algorithm: all-pairs
     Hamming -> identity -> pica2/h-fst/tj_d) on a bounded sample of the SAME windows, one host
@@ -90,7 +105,7 @@ def cpu_baseline(bm, windows, in_a, in_b, budget_s=12.0):
         n_sc += 1
         j += 1
     # the same port on every host core (OpenMP over windows) on a 64-window slab, repeated for ~3 s
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = host_cores()
     Wn = int(windows[0]["site_end"]) - int(windows[0]["site_begin"])
     n_slab = min(64, len(windows))
     uniform = all(int(w["site_end"]) - int(w["site_begin"]) == Wn and int(w["site_begin"]) == k * Wn

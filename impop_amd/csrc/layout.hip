@@ -170,7 +170,7 @@ static int alloc_matrix(impop_ctx *ctx, uint32_t n_hap, uint64_t n_site, bool wa
         return hip_fail(e, "hipMemsetAsync", __FILE__, __LINE__);
     }
     if (want_hm) {
-        m->rb_nb = m->g.n_block + 4;  // 64-site cells per row group + prefetch slack
+        m->rb_nb = m->g.n_block + 8;  // 64-site cells per row group + slack (a 4-cell Gram step may overhang the last cell)
         m->rb_bytes = (uint64_t)(m->n_hap_pad / 32) * m->rb_nb * 32ull * 8ull;
         e = hipMalloc((void **)&m->d_rb, m->rb_bytes);
         if (e != hipSuccess) {

@@ -4,7 +4,10 @@
 //
 // This path is VALU-bound, not HBM-bound: its roof is the popcount issue rate
 // (2 lane-ops per haplotype pair per 32 sites), reported separately from the scan.
+#include <stdlib.h>
+
 #include <algorithm>
+#include <type_traits>
 #include <vector>
 
 #include "stats_kernels.h"
@@ -230,6 +233,250 @@ __device__ __forceinline__ void gram_task(const uint32_t *__restrict__ rb, uint6
         }
 }
 
+// ---- Gram task on the FP4 matrix cores, straight from the raw bit planes (no table, no LDS) ------
+// v_mfma_f32_32x32x64_f8f6f4 with E2M1 operands runs K = 64 in the 32 cycles the int8 form needs for
+// K = 32 (tools/micro/fp4_probe.hip: 8.45 PFLOP/s over the chip), and a 0/1 matrix needs NO table
+// for it: the E2M1 nibble 0010 is 1.0, so the four vectors
+//     (x << 1) & 0x22222222,  x & 0x22222222,  (x >> 1) & 0x22222222,  (x >> 2) & 0x22222222
+// are valid FP4 operands that together hold every bit of the raw dword x exactly once: 7 VALU per 32
+// sites of a row instead of a v_perm + a 64 KB-table look-up per 8 sites.  The four planes of ONE raw
+// dword are the four operand dwords of one MFMA (K = 64: lane half 0 supplies 32 sites of cell c,
+// lane half 1 the same dword of cell c+1; A and B use the same mapping, so the order of sites inside
+// the sum is irrelevant).  fp32 accumulation of 0/1 products is exact below 2^24 (K-slices are
+// capped accordingly) and the result is converted to int32 once per task.
+// Lane (r = lane & 31, h = lane >> 5) supplies row r of each 32-row group.  RB32: one dwordx2 load of
+// a wave = cells c, c+1 of 32 rows = 512 contiguous bytes, and feeds two MFMA phases (dword 0, 1).
+// Three cell buffers rotate; a buffer is reloaded right after its last expansion, four phases
+// (4 x 9 MFMAs = 1152 cycles) before its next use.
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr uint32_t FP4_MAX_SLICE_PAIRS = (1u << 24) / 128;  // fp32 accumulators stay exact integers
+
+__device__ __forceinline__ i32x4 fp4_planes(uint32_t x) {
+    i32x4 f;
+    f.x = (int)((x << 1) & 0x22222222u);
+    f.y = (int)(x & 0x22222222u);
+    f.z = (int)((x >> 1) & 0x22222222u);
+    f.w = (int)((x >> 2) & 0x22222222u);
+    return f;
+}
+// the builtin takes 8 dwords per operand; FP4 uses the first 4 (the compiler allocates v[n:n+3])
+__device__ __forceinline__ i32x8 fp4_operand(const i32x4 f) { return (i32x8){f.x, f.y, f.z, f.w, 0, 0, 0, 0}; }
+
+typedef int i32x4v __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+template <bool DIAG>
+__device__ __forceinline__ void gram_task_fp4(const uint32_t *__restrict__ rb, uint64_t nb_row, uint32_t ti, uint32_t tj,
+                                              const GramWindow w, uint32_t ks, uint32_t ksplit, int32_t *__restrict__ o,
+                                              uint32_t ld) {
+    constexpr int NB = DIAG ? 0 : 3;
+    constexpr int NM = DIAG ? 6 : 9;  // MFMAs per phase
+    const uint32_t lane = threadIdx.x & 63, r32 = lane & 31, hi_half = lane >> 5;
+    f32x16 acc[3][3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+    if (w.site_end > w.site_begin) {
+        const uint64_t cell0 = w.site_begin >> 6;
+        const uint32_t ncell = (uint32_t)(((w.site_end + 63) >> 6) - cell0);
+        const uint32_t npair = (ncell + 1) >> 1;  // a pair = cells 2u, 2u+1 (one per lane half) = 128 sites
+        const uint32_t ubeg = (uint32_t)((uint64_t)npair * ks / ksplit);
+        const uint32_t uend = (uint32_t)((uint64_t)npair * (ks + 1) / ksplit);  // this K-slice: pairs [ubeg, uend)
+        const uint32_t f = (uint32_t)((w.site_begin >> 5) - 2 * cell0);           // first window dword (0 or 1)
+        const uint32_t l = (uint32_t)(((w.site_end + 31) >> 5) - 1 - 2 * cell0);  // last window dword
+        const uint32_t first_mask = 0xFFFFFFFFu << (w.site_begin & 31);
+        const uint32_t last_mask = (w.site_end & 31) ? (0xFFFFFFFFu >> (32 - (w.site_end & 31))) : 0xFFFFFFFFu;
+        auto mask_of = [&](uint32_t d, bool live) -> uint32_t {  // wave-uniform
+            uint32_t m = (live && d >= f && d <= l) ? 0xFFFFFFFFu : 0u;
+            if (d == f) m &= first_mask;
+            if (d == l) m &= last_mask;
+            return m;
+        };
+        const uint32_t hsel = hi_half ? 0xFFFFFFFFu : 0u;
+        auto lane_mask = [&](uint32_t u, int d) -> uint32_t {
+            const uint32_t d0 = 4 * u + d;  // dword index of lane half 0 (cell 2u); lane half 1 is one cell (2 dwords) on
+            return (hsel & mask_of(d0 + 2, u < uend)) | (~hsel & mask_of(d0, u < uend));
+        };
+        // Buffer loads: one descriptor per 32-row group, based at the slice's first pair (SGPRs only), the
+        // constant per-lane byte offset in voffset and the pair index in soffset: no address VALU at all.
+        // (a K-slice is at most FP4_MAX_SLICE_PAIRS * 512 B = 64 MB long, well inside the 32-bit offsets)
+        const uint64_t g32b = nb_row * 256;  // bytes between consecutive 32-row groups
+        const char *bA = reinterpret_cast<const char *>(rb) + (((uint64_t)(ti * 3) * nb_row + cell0) * 256 + (uint64_t)ubeg * 512);
+        const char *bB = reinterpret_cast<const char *>(rb) + (((uint64_t)(tj * 3) * nb_row + cell0) * 256 + (uint64_t)ubeg * 512);
+        __amdgpu_buffer_rsrc_t rA[3], rB[3];
+#pragma unroll
+        for (int g = 0; g < 3; ++g) {
+            rA[g] = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(bA + g * g32b), 0, 0x7FFFFFFF, 0x00020000);
+            rB[g] = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(bB + g * g32b), 0, 0x7FFFFFFF, 0x00020000);
+        }
+        const uint32_t lane_off = r32 * 8 + hi_half * 256;  // row r32's dword pair inside the lane half's cell
+        struct Cell {
+            u32x2 a[3], b[3];
+        };
+        struct Frag {  // four FP4 operand dwords per 32-row group, kept as scalars so that asm can define them singly
+            uint32_t a[3][4], b[3][4];
+        };
+        auto load_one = [&](Cell &C, int i, uint32_t soff) {  // i = 0..2: A groups, 3..5: B groups
+            if (i < 3) C.a[i] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rA[i], lane_off, soff, 0));
+            else C.b[i - 3] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rB[i - 3], lane_off, soff, 0));
+        };
+        auto pair_soff = [&](uint32_t u) -> uint32_t {  // clamp: never past the slice's last pair
+            return ((u < uend ? u : uend - 1) - ubeg) * 512u;
+        };
+        // The phase is scheduled BY HAND in volatile inline asm: builtins let the compiler float the
+        // expansion arithmetic across sched_barriers (it is not chained to them) and the MFMAs ended up
+        // in runs of 3-9 with the VALU work in one lump behind them.  Volatile asm statements keep their
+        // order, so the issue pattern below is the one that runs: MFMA i, then the 4-7 VALU of slot i.
+        // Hazards: a fragment register is written >= 7 MFMAs after its last MFMA read and read >= 1 phase
+        // after it was written; an accumulator is touched every 9th (6th) MFMA; the compiler cannot see
+        // into the asm, so the prologue / epilogue are fenced with explicit s_nop below.
+        auto mfma_asm = [](f32x16 &c, const uint32_t (&fa)[4], const uint32_t (&fb)[4]) {
+            const i32x4 va = {(int)fa[0], (int)fa[1], (int)fa[2], (int)fa[3]};
+            const i32x4 vb = {(int)fb[0], (int)fb[1], (int)fb[2], (int)fb[3]};
+            asm volatile("v_mfma_f32_32x32x64_f8f6f4 %0, %1, %2, %0 cbsz:4 blgp:4" : "+v"(c) : "v"(va), "v"(vb));
+        };
+        auto lo_masked = [](uint32_t (&fr)[4], uint32_t &xm, uint32_t x, uint32_t m) {  // planes 0, 1 of x & m (4 VALU)
+            asm volatile("v_and_b32 %2, %3, %4\n\tv_lshlrev_b32 %0, 1, %2\n\tv_and_b32 %0, 0x22222222, %0\n\tv_and_b32 %1, 0x22222222, %2"
+                         : "=&v"(fr[0]), "=&v"(fr[1]), "=&v"(xm) : "v"(x), "v"(m));
+        };
+        auto lo_plain = [](uint32_t (&fr)[4], uint32_t x) {  // planes 0, 1 (3 VALU)
+            asm volatile("v_lshlrev_b32 %0, 1, %2\n\tv_and_b32 %0, 0x22222222, %0\n\tv_and_b32 %1, 0x22222222, %2"
+                         : "=&v"(fr[0]), "=&v"(fr[1]) : "v"(x));
+        };
+        auto hi_planes = [](uint32_t (&fr)[4], uint32_t x) {  // planes 2, 3 (4 VALU)
+            asm volatile("v_lshrrev_b32 %0, 1, %2\n\tv_and_b32 %0, 0x22222222, %0\n\tv_lshrrev_b32 %1, 2, %2\n\tv_and_b32 %1, 0x22222222, %1"
+                         : "=&v"(fr[2]), "=&v"(fr[3]) : "v"(x));
+        };
+#define FP4_PHASE(CURF, NXTF, SRC, D, M, LOADC, SOFF, DO_LOAD)                                            \
+    do {                                                                                                  \
+        uint32_t xa0 = 0, xa1 = 0, xa2 = 0;                                                               \
+        _Pragma("unroll") for (int i = 0; i < NM; ++i) {                                                  \
+            const int a = DIAG ? (i < 3 ? 0 : i < 5 ? 1 : 2) : i / 3;                                     \
+            const int b = DIAG ? (i < 3 ? i : i < 5 ? i - 2 : 2) : i % 3;                                 \
+            if (DIAG) mfma_asm(acc[a][b], CURF.a[a], CURF.a[b]);                                          \
+            else mfma_asm(acc[a][b], CURF.a[a], CURF.b[b]);                                               \
+            if (DO_LOAD && i < (DIAG ? 3 : 6)) load_one(LOADC, i, SOFF);                                  \
+            if (DIAG) {                                                                                   \
+                if (i == 0) lo_masked(NXTF.a[0], xa0, D ? SRC.a[0].y : SRC.a[0].x, M);                    \
+                if (i == 1) hi_planes(NXTF.a[0], xa0);                                                    \
+                if (i == 2) lo_masked(NXTF.a[1], xa1, D ? SRC.a[1].y : SRC.a[1].x, M);                    \
+                if (i == 3) hi_planes(NXTF.a[1], xa1);                                                    \
+                if (i == 4) lo_masked(NXTF.a[2], xa2, D ? SRC.a[2].y : SRC.a[2].x, M);                    \
+                if (i == 5) hi_planes(NXTF.a[2], xa2);                                                    \
+            } else {                                                                                      \
+                if (i == 0) lo_masked(NXTF.a[0], xa0, D ? SRC.a[0].y : SRC.a[0].x, M);                    \
+                if (i == 1) { hi_planes(NXTF.a[0], xa0); lo_plain(NXTF.b[0], D ? SRC.b[0].y : SRC.b[0].x); } \
+                if (i == 2) hi_planes(NXTF.b[0], D ? SRC.b[0].y : SRC.b[0].x);                            \
+                if (i == 3) lo_masked(NXTF.a[1], xa1, D ? SRC.a[1].y : SRC.a[1].x, M);                    \
+                if (i == 4) { hi_planes(NXTF.a[1], xa1); lo_plain(NXTF.b[1], D ? SRC.b[1].y : SRC.b[1].x); } \
+                if (i == 5) hi_planes(NXTF.b[1], D ? SRC.b[1].y : SRC.b[1].x);                            \
+                if (i == 6) lo_masked(NXTF.a[2], xa2, D ? SRC.a[2].y : SRC.a[2].x, M);                    \
+                if (i == 7) { hi_planes(NXTF.a[2], xa2); lo_plain(NXTF.b[2], D ? SRC.b[2].y : SRC.b[2].x); } \
+                if (i == 8) hi_planes(NXTF.b[2], D ? SRC.b[2].y : SRC.b[2].x);                            \
+            }                                                                                             \
+        }                                                                                                 \
+    } while (0)
+        // pair U lives in CUR (its dword 0 is already expanded in F); NXT holds pair U+1.  The mask
+        // arithmetic sits behind a wave-uniform branch that only edge pairs take (the empty volatile asm
+        // keeps the compiler from turning it back into always-executed selects); the MFMA code is common.
+#define FP4_PAIR(CUR, NXT, U)                                                       \
+    do {                                                                            \
+        uint32_t mA = 0xFFFFFFFFu, mB = 0xFFFFFFFFu;                                \
+        if (!(4 * (U) + 1 > f && 4 * (U) + 6 < l && (U) + 1 < uend)) {              \
+            asm volatile("");                                                       \
+            mA = lane_mask((U), 1);                                                 \
+            mB = lane_mask((U) + 1, 0);                                             \
+        }                                                                           \
+        const uint32_t soff = pair_soff((U) + 3);                                   \
+        FP4_PHASE(F, G, CUR, 1, mA, CUR, soff, false);                              \
+        FP4_PHASE(G, F, NXT, 0, mB, CUR, soff, true);                               \
+    } while (0)
+        if (ubeg < uend) {
+            Cell C0, C1, C2;
+            Frag F, G;
+#pragma unroll
+            for (int i = 0; i < (DIAG ? 3 : 6); ++i) {
+                load_one(C0, i, pair_soff(ubeg));
+                load_one(C1, i, pair_soff(ubeg + 1));
+                load_one(C2, i, pair_soff(ubeg + 2));
+            }
+            {
+                const uint32_t m0 = lane_mask(ubeg, 0);
+                uint32_t xm;
+#pragma unroll
+                for (int g = 0; g < 3; ++g) {
+                    lo_masked(F.a[g], xm, C0.a[g].x, m0);
+                    hi_planes(F.a[g], xm);
+                }
+#pragma unroll
+                for (int g = 0; g < NB; ++g) {
+                    lo_plain(F.b[g], C0.b[g].x);
+                    hi_planes(F.b[g], C0.b[g].x);
+                }
+                asm volatile("s_nop 7");  // VALU-written operands -> first MFMA (the compiler cannot see into the asm)
+            }
+            // no early exit (extra loop exits make the compiler merge 144 accumulators and spill): a slice
+            // whose length is not a multiple of 3 pairs runs up to two fully masked pairs
+            for (uint32_t u = ubeg; u < uend; u += 3) {
+                FP4_PAIR(C0, C1, u);
+                FP4_PAIR(C1, C2, u + 1);
+                FP4_PAIR(C2, C0, u + 2);
+            }
+        }
+#undef FP4_PAIR
+#undef FP4_PHASE
+        asm volatile("s_nop 15\n\ts_nop 15");  // last MFMA results -> the VALU conversions below
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+            if (DIAG && b < a) continue;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const uint32_t row = ti * GT + 32 * a + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+                const uint32_t col = tj * GT + 32 * b + r32;
+                const int32_t v = (int32_t)acc[a][b][e];
+                if (ksplit == 1) o[(uint64_t)row * ld + col] = v;
+                else atomicAdd(&o[(uint64_t)row * ld + col], v);
+            }
+        }
+}
+
+// Persistent FP4 Gram kernel: same task queues as gram_mfma_kernel below, no LDS at all.
+__global__ __launch_bounds__(256, 2) void gram_fp4_kernel(const uint32_t *__restrict__ rb, uint64_t nb_row, uint32_t n_tiles,
+                                                          uint32_t tasks_per_win, uint32_t n_win, uint32_t ksplit,
+                                                          const GramWindow *__restrict__ wins, int32_t *__restrict__ out,
+                                                          uint32_t ld, uint64_t out_stride, uint32_t *__restrict__ queue_heads) {
+    const uint32_t slots = tasks_per_win * ksplit;
+    const bool by_window = n_win >= 8;
+    const uint64_t total = (uint64_t)n_win * slots;
+    for (uint32_t dq = 0; dq < 8; ++dq) {
+        const uint32_t q = (blockIdx.x + dq) & 7;
+        const uint64_t q_len = by_window ? (uint64_t)((n_win + 7 - q) / 8) * slots : (total + 7 - q) / 8;
+        for (;;) {
+            uint32_t k = 0;
+            if ((threadIdx.x & 63) == 0) k = atomicAdd(&queue_heads[q], 1u);
+            k = __builtin_amdgcn_readfirstlane(k);
+            if (k >= q_len) break;
+            uint32_t win, t2;
+            if (by_window) { win = q + 8 * (k / slots); t2 = k % slots; }
+            else { const uint64_t i = q + 8ull * k; win = (uint32_t)(i / slots); t2 = (uint32_t)(i % slots); }
+            const uint32_t ks = t2 % ksplit;
+            uint32_t rem = t2 / ksplit, ti = 0;
+            while (rem >= n_tiles - ti) { rem -= n_tiles - ti; ++ti; }
+            const uint32_t tj = ti + rem;
+            int32_t *o = out + (uint64_t)win * out_stride;
+            if (ti == tj) gram_task_fp4<true>(rb, nb_row, ti, tj, wins[win], ks, ksplit, o, ld);
+            else gram_task_fp4<false>(rb, nb_row, ti, tj, wins[win], ks, ksplit, o, ld);
+        }
+    }
+}
+
 // Persistent workgroups (2 per CU, 4 waves each) that share only the lookup table; every WAVE pulls
 // (window, tile pair, K-slice) tasks from one of 8 queues until all are drained, so a wave whose task
 // was short (diagonal tiles do 2/3 of the MFMAs) immediately starts another one and both SIMD slots
@@ -323,7 +570,17 @@ __global__ void pairwise_finalize_kernel(PairFinalIn in, uint64_t n_windows, uin
     out[i] = r;
 }
 
-static int launch_gram(impop_ctx *ctx, const impop_matrix *m, const GramWindow *d_wins, uint32_t n_win, int32_t *d_out) {
+// IMPOP_GRAM_MFMA=i8 selects the int8 kernel (kept for A/B measurements); default: FP4 bit planes
+static bool gram_use_fp4() {
+    static const bool v = [] {
+        const char *e = getenv("IMPOP_GRAM_MFMA");
+        return !(e && e[0] == 'i');
+    }();
+    return v;
+}
+
+static int launch_gram(impop_ctx *ctx, const impop_matrix *m, const GramWindow *d_wins, uint32_t n_win, int32_t *d_out,
+                       uint64_t max_window_sites) {
     const uint32_t T = m->n_hap_pad / GT;
     const uint32_t tasks_per_win = T * (T + 1) / 2;  // upper-triangular tile pairs
     // two waves per SIMD on every CU = 8 * n_cu resident waves; aim at >= 4 rounds of them so the
@@ -331,6 +588,8 @@ static int launch_gram(impop_ctx *ctx, const impop_matrix *m, const GramWindow *
     const uint64_t want = 32ull * (uint64_t)(ctx->n_cu > 0 ? ctx->n_cu : 256);
     uint32_t ksplit = 1;
     while ((uint64_t)n_win * tasks_per_win * ksplit < want && ksplit < 64) ksplit *= 2;
+    // FP4: fp32 accumulators must stay below 2^24 per K-slice
+    while (gram_use_fp4() && (max_window_sites / 128 + 2) / ksplit + 1 > FP4_MAX_SLICE_PAIRS) ksplit *= 2;
     if (ksplit > 1)
         HIP_TRY(hipMemsetAsync(d_out, 0, (size_t)n_win * m->n_hap_pad * m->n_hap_pad * sizeof(int32_t), ctx->stream));
     REQUIRE((uint64_t)n_win * tasks_per_win * ksplit < 0xFFFFFFF0ull, "gram: too many tasks for one launch");
@@ -340,8 +599,12 @@ static int launch_gram(impop_ctx *ctx, const impop_matrix *m, const GramWindow *
     const uint32_t n_cu = (uint32_t)(ctx->n_cu > 0 ? ctx->n_cu : 256);
     const uint64_t need_wg = ((uint64_t)n_win * tasks_per_win * ksplit + 3) / 4;
     const uint32_t grid = (uint32_t)std::max<uint64_t>(8, std::min<uint64_t>(2ull * n_cu, need_wg));
-    hipLaunchKernelGGL(gram_mfma_kernel, dim3(grid), dim3(256), 0, ctx->stream, m->d_rb, m->rb_nb, T, tasks_per_win, n_win,
-                       ksplit, d_wins, d_out, m->n_hap_pad, (uint64_t)m->n_hap_pad * m->n_hap_pad, ctx->d_queue);
+    if (gram_use_fp4())
+        hipLaunchKernelGGL(gram_fp4_kernel, dim3(grid), dim3(256), 0, ctx->stream, m->d_rb, m->rb_nb, T, tasks_per_win, n_win,
+                           ksplit, d_wins, d_out, m->n_hap_pad, (uint64_t)m->n_hap_pad * m->n_hap_pad, ctx->d_queue);
+    else
+        hipLaunchKernelGGL(gram_mfma_kernel, dim3(grid), dim3(256), 0, ctx->stream, m->d_rb, m->rb_nb, T, tasks_per_win, n_win,
+                           ksplit, d_wins, d_out, m->n_hap_pad, (uint64_t)m->n_hap_pad * m->n_hap_pad, ctx->d_queue);
     HIP_TRY(hipGetLastError());
     return IMPOP_OK;
 }
@@ -387,7 +650,7 @@ IMPOP_API int impop_pairwise_counts(impop_ctx *ctx, const impop_matrix *m, uint6
     int32_t *d_g = cv.take<int32_t>((size_t)ld * ld);
     GramWindow w{site_begin, site_end};
     HIP_TRY(hipMemcpyAsync(d_w, &w, sizeof w, hipMemcpyHostToDevice, ctx->stream));
-    rc = launch_gram(ctx, m, d_w, 1, d_g);
+    rc = launch_gram(ctx, m, d_w, 1, d_g, site_end - site_begin);
     if (rc) return rc;
     hipLaunchKernelGGL(gram_symmetrize_kernel, dim3((ld + 15) / 16, (ld + 15) / 16), dim3(16, 16), 0, ctx->stream, d_g, ld);
     HIP_TRY(hipGetLastError());
@@ -418,7 +681,7 @@ IMPOP_API int impop_pairwise_identity(impop_ctx *ctx, const impop_matrix *m, uin
     const uint64_t W = site_end - site_begin;
     HIP_TRY(hipMemcpyAsync(d_w, &w, sizeof w, hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(hipMemcpyAsync(d_W, &W, 8, hipMemcpyHostToDevice, ctx->stream));
-    rc = launch_gram(ctx, m, d_w, 1, d_g);
+    rc = launch_gram(ctx, m, d_w, 1, d_g, site_end - site_begin);
     if (rc) return rc;
     SimBatch b{};
     b.gram = d_g; b.stride = (uint64_t)ld * ld; b.ld = ld; b.n = n; b.W = d_W; b.kind = identity_kind; b.round_digits = -1;
@@ -468,9 +731,10 @@ IMPOP_API int impop_pairwise_scan(impop_ctx *ctx, const impop_matrix *m, const i
         fb[i] = mask_b ? (uint8_t)((mask_b[i >> 6] >> (i & 63)) & 1ull) : 0;
     }
     const uint32_t nP = (uint32_t)idx.size();
-    // windows are processed in chunks so the Gram scratch stays bounded (<= ~1 GiB)
+    // windows are processed in chunks so the Gram scratch stays bounded (<= ~4 GiB of 288): large chunks keep
+    // the persistent Gram grid's last, partially filled round of tasks small next to the whole launch
     const size_t gram_bytes = (size_t)ld * ld * 4;
-    uint64_t chunk = (1ull << 30) / gram_bytes;
+    uint64_t chunk = (4ull << 30) / gram_bytes;
     if (chunk < 1) chunk = 1;
     if (chunk > 4096) chunk = 4096;
     if (chunk > n_windows) chunk = n_windows;
@@ -507,7 +771,9 @@ IMPOP_API int impop_pairwise_scan(impop_ctx *ctx, const impop_matrix *m, const i
     std::vector<uint64_t> Wv(chunk), Lv(chunk);
     for (uint64_t base = 0; base < n_windows; base += chunk) {
         const uint64_t cnt = std::min<uint64_t>(chunk, n_windows - base);
+        uint64_t max_sites = 0;
         for (uint64_t k = 0; k < cnt; ++k) {
+            max_sites = std::max<uint64_t>(max_sites, windows[base + k].site_end - windows[base + k].site_begin);
             gw[k] = {windows[base + k].site_begin, windows[base + k].site_end};
             Wv[k] = windows[base + k].site_end - windows[base + k].site_begin;
             Lv[k] = windows[base + k].seq_len;
@@ -517,7 +783,7 @@ IMPOP_API int impop_pairwise_scan(impop_ctx *ctx, const impop_matrix *m, const i
         PW_TRY(hipMemcpyAsync(d_L, Lv.data(), cnt * 8, hipMemcpyHostToDevice, ctx->stream));
         PW_TRY(hipMemcpyAsync(d_s, scan_host.data() + base, cnt * sizeof(impop_window_stats), hipMemcpyHostToDevice,
                               ctx->stream));
-        rc = launch_gram(ctx, m, d_w, (uint32_t)cnt, d_g);
+        rc = launch_gram(ctx, m, d_w, (uint32_t)cnt, d_g, max_sites);
         if (rc) return fail(rc);
         SimBatch b{};
         b.gram = d_g; b.stride = (uint64_t)ld * ld; b.ld = ld; b.n = n; b.W = d_W; b.kind = params->identity_kind;

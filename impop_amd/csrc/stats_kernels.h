@@ -31,6 +31,7 @@ struct SimView {
     // for H < tbl_n (same arithmetic, hence bit-identical values) instead of once per pair
     const double *tbl;
     uint32_t tbl_n;
+    const int32_t *diag;  // optional LDS copy of the Gram diagonal a_i (else read from `gram`)
 };
 
 constexpr uint32_t SIM_TBL_N = 4096;
@@ -62,6 +63,7 @@ __device__ inline SimView sim_view(const SimBatch &b, uint64_t p) {
     v.round_digits = b.round_digits;
     v.tbl = nullptr;
     v.tbl_n = 0;
+    v.diag = nullptr;
     return v;
 }
 
@@ -73,7 +75,8 @@ __device__ inline double sim_get(const SimView &S, uint32_t i, uint32_t j) {
         v = S.dense[(uint64_t)i * S.ld + j];
     } else {
         const int64_t I = S.gram[(uint64_t)i * S.ld + j];
-        const int64_t ai = S.gram[(uint64_t)i * S.ld + i], aj = S.gram[(uint64_t)j * S.ld + j];
+        const int64_t ai = S.diag ? S.diag[i] : S.gram[(uint64_t)i * S.ld + i];
+        const int64_t aj = S.diag ? S.diag[j] : S.gram[(uint64_t)j * S.ld + j];
         if (S.kind == IMPOP_IDENTITY_MATCH) {
             const int64_t H = ai + aj - 2 * I;
             if ((uint64_t)H < S.tbl_n) return S.tbl[H];  // memoised (already rounded)

@@ -14,6 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 VALU_PEAK_LANEOPS = 256 * 128 * 2.4e9  # 256 CUs x 128 lane-ops/clk x 2.4 GHz (MI355X_MICROARCH.md)
+FP4_DENSE_PEAK_MACS = 5.0e15           # ~10 PFLOP/s dense FP4 (MI355X_MICROARCH.md) = 5e15 MAC/s
 
 
 def main():
@@ -49,8 +50,11 @@ def main():
     pi, ps, _, G = orc.pica2(sim, 0.999, W, 5)
     assert args.no_check or (abs(float(res[0]["pi"]) - pi) <= 1e-9 * abs(pi) and int(res[0]["n_groups"]) == G), (res[0], pi, G)
     pair_words = (n * (n + 1) // 2) * ((W + 31) // 32)
+    macs = n * (n + 1) // 2 * W  # algorithmic MACs per window (upper triangle incl. diagonal)
     out["pairwise_scan_465x50kb"] = {"windows": NW, "s_per_batch": dt, "windows_per_s": NW / dt, "groups_window0": G,
-                                     "algorithmic_lane_ops_per_window": 2 * pair_words}
+                                     "algorithmic_macs_per_window": macs, "algorithmic_macs_per_s": macs * NW / dt,
+                                     "frac_of_fp4_dense_peak_end_to_end": macs * NW / dt / FP4_DENSE_PEAK_MACS,
+                                     "gram_kernel": os.environ.get("IMPOP_GRAM_MFMA", "fp4")}
     bm.free()
     # ---- config 5 shape: 4096 haplotypes, one long window, integer Gram only
     nb, Wb = args.big_hap, args.big_sites
@@ -67,9 +71,9 @@ def main():
     want = m[idx] @ m.T
     assert args.no_check or (Ic[idx].astype(np.int64) == want).all()
     pair_words = (nb * (nb + 1) // 2) * ((Wb + 31) // 32)
-    out["gram_%dx%d" % (nb, Wb)] = {"s_incl_copy_out": dt, "algorithmic_lane_ops": 2 * pair_words,
-                                    "lane_ops_per_s_incl_copy": 2 * pair_words / dt,
-                                    "frac_of_valu_peak_incl_copy": 2 * pair_words / dt / VALU_PEAK_LANEOPS}
+    macs_b = nb * (nb + 1) // 2 * Wb
+    out["gram_%dx%d" % (nb, Wb)] = {"s_incl_copy_out": dt, "algorithmic_macs": macs_b, "macs_per_s_incl_copy": macs_b / dt,
+                                    "frac_of_fp4_dense_peak_incl_copy": macs_b / dt / FP4_DENSE_PEAK_MACS}
     print(json.dumps(out))
     bm.free()
     ctx.close()

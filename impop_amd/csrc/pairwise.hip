@@ -2,8 +2,9 @@
 // window, then the full pica2 / h-fst semantics (thresholds, rounding,
 // greedy grouping) on identities formed on the fly from the integer Gram matrix.
 //
-// This path is VALU-bound, not HBM-bound: its roof is the popcount issue rate
-// (2 lane-ops per haplotype pair per 32 sites), reported separately from the scan.
+// This path is MFMA-bound, not HBM-bound.  Shipped Gram kernel: gram_fp4_kernel
+// (FP4 bit planes, further down); gram_mfma_kernel (int8 + look-up table) is its predecessor,
+// selectable with IMPOP_GRAM_MFMA=i8 for A/B measurements.
 #include <stdlib.h>
 
 #include <algorithm>

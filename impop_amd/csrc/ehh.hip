@@ -111,6 +111,7 @@ using namespace impop;
 IMPOP_API int impop_ehh(impop_ctx *ctx, const impop_matrix *m, uint64_t site_begin, uint64_t site_end, const uint64_t *mask,
                         int reverse, double *ehh_out_host, uint32_t *n_members) {
     REQUIRE(ctx && m, "impop_ehh: NULL argument");
+    NOT_COMPACT(m, "impop_ehh");
     REQUIRE(site_begin <= site_end && site_end <= m->g.n_site, "impop_ehh: bad site range");
     HIP_TRY(hipSetDevice(ctx->device));
     const uint32_t n = m->g.n_hap;

@@ -29,6 +29,15 @@ int hip_fail(hipError_t e, const char *what, const char *file, int line);
         }                                  \
     } while (0)
 
+// per-site outputs and the all-pairs path need every site: they refuse compacted matrices
+#define NOT_COMPACT(m, fn)                                                                                     \
+    do {                                                                                                       \
+        if ((m)->compact) {                                                                                    \
+            impop::set_error("%s: not available on a compacted matrix (impop_matrix_compact drops monomorphic sites)", fn); \
+            return IMPOP_E_UNSUPPORTED;                                                                        \
+        }                                                                                                      \
+    } while (0)
+
 // ---- SB64: site-blocked, wave-interleaved layout --------------------------------
 // The site axis is cut into blocks of 64 sites (one wavefront).  A site holds
 // wps = ceil(n_hap/32) dwords (dword k = haplotypes 32k..32k+31).  Inside a block the
@@ -86,6 +95,11 @@ struct impop_matrix {
     uint64_t rb_nb = 0;         // cells per row group incl. 4 cells of slack (prefetch)
     uint32_t n_hap_pad = 0;     // rows padded to a multiple of 96 (zero rows; Gram tiles are 96 wide)
     uint64_t rb_bytes = 0;
+    // compacted matrix (impop_matrix_compact): only the sites variable among all haplotypes were kept;
+    // pos[k] = original index of kept site k (host copy for window mapping), n_site_orig = original length
+    bool compact = false;
+    uint64_t n_site_orig = 0;
+    std::vector<uint64_t> pos;
     int device = 0;
     mutable int users = 0;      // live scan plans referencing this matrix (impop_matrix_free refuses while > 0)
 };
@@ -93,6 +107,11 @@ struct impop_matrix {
 namespace impop {
 int ctx_scratch(impop_ctx *ctx, size_t bytes, void **out);
 int ensure_tajima_consts(impop_ctx *ctx, int64_t n);  // fills ctx->d_taj for n (device kernel)
+
+// windows are given in ORIGINAL site coordinates; for a compacted matrix map them to kept-site index
+// ranges (`mapped`), else `mapped` is a plain copy.  span() = the coordinate range windows must lie in.
+inline uint64_t matrix_span(const impop_matrix *m) { return m->compact ? m->n_site_orig : m->g.n_site; }
+void map_windows(const impop_matrix *m, const impop_window *windows, uint64_t n, std::vector<impop_window> &mapped);
 
 // layout.hip
 int launch_hm_to_sb(impop_ctx *ctx, const uint32_t *d_hm, uint64_t hm_stride, const SbGeom &g, uint32_t *d_sb);

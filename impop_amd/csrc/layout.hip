@@ -6,6 +6,8 @@
 
 #include <vector>
 
+#include <algorithm>
+
 #include "device_utils.h"
 #include "internal.h"
 
@@ -331,6 +333,160 @@ IMPOP_API int impop_matrix_download(impop_ctx *ctx, const impop_matrix *m, uint6
         }
         if (W & 63) dst[out_words - 1] &= (~0ull) >> (64 - (W & 63));
     }
+    return IMPOP_OK;
+}
+
+// ---- compaction to the variable sites ------------------------------------------------------------
+// Monomorphic sites (c_s = 0 or c_s = n over ALL haplotypes) add 0 to every sum_s c(n - c) of every
+// subset and are never segregating, so the scan statistics of a window depend on its variable sites
+// and its LENGTH only.  A compacted matrix keeps those sites (with their original positions) and is
+// scanned with windows in the original coordinates: same records, ~W/S times fewer bytes.
+namespace impop {
+
+__global__ __launch_bounds__(256) void variable_mask_kernel(const uint32_t *__restrict__ sb, uint32_t wps, uint32_t G,
+                                                            uint32_t r, uint64_t n_block, uint64_t n_site, uint32_t n_hap,
+                                                            uint64_t *__restrict__ mask, uint32_t *__restrict__ cnt) {
+    const uint32_t lane = threadIdx.x & 63;
+    const uint64_t b = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= n_block) return;
+    uint32_t c = 0;
+    for (uint32_t k = 0; k < wps; ++k) c += __popc(sb[sb_index(wps, G, r, b, lane, k)]);
+    const bool var = (b * 64 + lane < n_site) && c > 0 && c < n_hap;
+    const uint64_t m = __ballot(var);
+    if (lane == 0) { mask[b] = m; cnt[b] = (uint32_t)__popcll(m); }
+}
+
+constexpr uint32_t SCAN_CHUNK = 1024;  // blocks per workgroup in the two-level exclusive scan
+__global__ __launch_bounds__(256) void chunk_sum_kernel(const uint32_t *__restrict__ cnt, uint64_t n, uint64_t *__restrict__ chunk_sum) {
+    __shared__ uint64_t sh[4];
+    const uint64_t base = (uint64_t)blockIdx.x * SCAN_CHUNK;
+    uint64_t t = 0;
+    for (uint32_t i = threadIdx.x; i < SCAN_CHUNK; i += 256)
+        if (base + i < n) t += cnt[base + i];
+    t = wave_sum_u64(t);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = t;
+    __syncthreads();
+    if (threadIdx.x == 0) chunk_sum[blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
+}
+__global__ void chunk_scan_kernel(uint64_t *chunk_sum, uint64_t n_chunks, uint64_t *total) {  // one thread: n_chunks is small
+    if (threadIdx.x || blockIdx.x) return;
+    uint64_t run = 0;
+    for (uint64_t i = 0; i < n_chunks; ++i) {
+        const uint64_t v = chunk_sum[i];
+        chunk_sum[i] = run;
+        run += v;
+    }
+    *total = run;
+}
+__global__ __launch_bounds__(64) void block_base_kernel(const uint32_t *__restrict__ cnt, uint64_t n, const uint64_t *__restrict__ chunk_off,
+                                                        uint64_t *__restrict__ base) {
+    // one wave per chunk: 16 rounds of a 64-wide exclusive scan
+    const uint64_t b0 = (uint64_t)blockIdx.x * SCAN_CHUNK;
+    uint64_t run = chunk_off[blockIdx.x];
+    for (uint32_t rnd = 0; rnd < SCAN_CHUNK / 64; ++rnd) {
+        const uint64_t i = b0 + rnd * 64 + threadIdx.x;
+        const uint64_t v = i < n ? cnt[i] : 0;
+        uint64_t incl = v;
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint64_t o = __shfl_up(incl, off, 64);
+            if ((int)threadIdx.x >= off) incl += o;
+        }
+        if (i < n) base[i] = run + incl - v;
+        run += __shfl(incl, 63, 64);
+    }
+}
+__global__ __launch_bounds__(256) void gather_variable_kernel(const uint32_t *__restrict__ sb, uint32_t wps, uint32_t G, uint32_t r,
+                                                              uint64_t n_block, const uint64_t *__restrict__ mask,
+                                                              const uint64_t *__restrict__ base, uint32_t *__restrict__ out,
+                                                              uint64_t *__restrict__ pos) {
+    const uint32_t lane = threadIdx.x & 63;
+    const uint64_t b = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= n_block) return;
+    const uint64_t m = mask[b];
+    if (!((m >> lane) & 1ull)) return;
+    const uint64_t dest = base[b] + (uint64_t)__popcll(m & ((1ull << lane) - 1ull));
+    for (uint32_t k = 0; k < wps; ++k)
+        out[sb_index(wps, G, r, dest >> 6, (uint32_t)(dest & 63), k)] = sb[sb_index(wps, G, r, b, lane, k)];
+    pos[dest] = b * 64 + lane;
+}
+
+void map_windows(const impop_matrix *m, const impop_window *windows, uint64_t n, std::vector<impop_window> &mapped) {
+    mapped.assign(windows, windows + n);
+    if (!m->compact) return;
+    for (uint64_t i = 0; i < n; ++i) {
+        mapped[i].site_begin = (uint64_t)(std::lower_bound(m->pos.begin(), m->pos.end(), windows[i].site_begin) - m->pos.begin());
+        mapped[i].site_end = (uint64_t)(std::lower_bound(m->pos.begin(), m->pos.end(), windows[i].site_end) - m->pos.begin());
+    }
+}
+
+}  // namespace impop
+
+IMPOP_API int impop_matrix_compact(impop_ctx *ctx, const impop_matrix *in, impop_matrix **out) {
+    REQUIRE(ctx && in && out, "impop_matrix_compact: NULL argument");
+    *out = nullptr;
+    REQUIRE(!in->compact, "impop_matrix_compact: matrix is already compacted");
+    HIP_TRY(hipSetDevice(ctx->device));
+    const SbGeom &g = in->g;
+    const uint64_t nb = g.n_block, n_chunks = (nb + SCAN_CHUNK - 1) / SCAN_CHUNK;
+    REQUIRE((nb + 3) / 4 < 0x7FFFFFFFull, "impop_matrix_compact: matrix too long for one launch");
+    auto up = [](size_t x) { return (x + 255) / 256 * 256; };
+    const size_t o_mask = 0, o_cnt = o_mask + up(nb * 8), o_base = o_cnt + up(nb * 4), o_chunk = o_base + up(nb * 8),
+                 o_total = o_chunk + up(n_chunks * 8);
+    void *d = nullptr;
+    int rc = ctx_scratch(ctx, o_total + 256, &d);
+    if (rc) return rc;
+    uint64_t *d_mask = (uint64_t *)((char *)d + o_mask), *d_base = (uint64_t *)((char *)d + o_base),
+             *d_chunk = (uint64_t *)((char *)d + o_chunk), *d_total = (uint64_t *)((char *)d + o_total);
+    uint32_t *d_cnt = (uint32_t *)((char *)d + o_cnt);
+    uint64_t n_kept = 0;
+    if (nb) {
+        hipLaunchKernelGGL(variable_mask_kernel, dim3((uint32_t)((nb + 3) / 4)), dim3(256), 0, ctx->stream, in->d_sb, g.wps, g.G, g.r,
+                           nb, g.n_site, g.n_hap, d_mask, d_cnt);
+        hipLaunchKernelGGL(chunk_sum_kernel, dim3((uint32_t)n_chunks), dim3(256), 0, ctx->stream, d_cnt, nb, d_chunk);
+        hipLaunchKernelGGL(chunk_scan_kernel, dim3(1), dim3(64), 0, ctx->stream, d_chunk, n_chunks, d_total);
+        hipLaunchKernelGGL(block_base_kernel, dim3((uint32_t)n_chunks), dim3(64), 0, ctx->stream, d_cnt, nb, d_chunk, d_base);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(&n_kept, d_total, 8, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+    }
+    impop_matrix *m = nullptr;
+    rc = alloc_matrix(ctx, g.n_hap, n_kept, false, &m);
+    if (rc) return rc;
+    auto fail = [&](int code) {
+        impop_matrix_free(ctx, m);
+        return code;
+    };
+    m->compact = true;
+    m->n_site_orig = g.n_site;
+    m->pos.resize(n_kept);
+    if (n_kept) {
+        uint64_t *d_pos = nullptr;
+        hipError_t e = hipMalloc((void **)&d_pos, n_kept * 8);
+        if (e != hipSuccess) return fail(hip_fail(e, "hipMalloc(positions)", __FILE__, __LINE__));
+        auto fail2 = [&](hipError_t err, const char *what) {
+            hipFree(d_pos);
+            return fail(hip_fail(err, what, __FILE__, __LINE__));
+        };
+        if ((e = hipMemsetAsync(m->d_sb, 0, m->sb_bytes, ctx->stream)) != hipSuccess) return fail2(e, "hipMemsetAsync");
+        hipLaunchKernelGGL(gather_variable_kernel, dim3((uint32_t)((nb + 3) / 4)), dim3(256), 0, ctx->stream, in->d_sb, g.wps, g.G,
+                           g.r, nb, d_mask, d_base, m->d_sb, d_pos);
+        if ((e = hipGetLastError()) != hipSuccess) return fail2(e, "gather_variable_kernel");
+        if ((e = hipMemcpyAsync(m->pos.data(), d_pos, n_kept * 8, hipMemcpyDeviceToHost, ctx->stream)) != hipSuccess)
+            return fail2(e, "hipMemcpyAsync(positions)");
+        if ((e = hipStreamSynchronize(ctx->stream)) != hipSuccess) return fail2(e, "hipStreamSynchronize");
+        hipFree(d_pos);
+    }
+    *out = m;
+    return IMPOP_OK;
+}
+
+IMPOP_API int impop_matrix_positions(const impop_matrix *m, uint64_t first, uint64_t count, uint64_t *out, uint64_t *n_site_orig) {
+    REQUIRE(m, "impop_matrix_positions: matrix is NULL");
+    REQUIRE(m->compact, "impop_matrix_positions: not a compacted matrix");
+    REQUIRE(first <= m->pos.size() && count <= m->pos.size() - first, "impop_matrix_positions: range out of bounds");
+    REQUIRE(count == 0 || out, "impop_matrix_positions: out is NULL");
+    for (uint64_t i = 0; i < count; ++i) out[i] = m->pos[first + i];
+    if (n_site_orig) *n_site_orig = m->n_site_orig;
     return IMPOP_OK;
 }
 

@@ -591,10 +591,10 @@ IMPOP_API int impop_scan_plan_create(impop_ctx *ctx, const impop_matrix *m, cons
     REQUIRE(tile_blocks <= 4096, "impop_scan_params.tile_blocks too large");
     if (m->g.wps > 16 && tile_blocks > 4 * SB_MAX) tile_blocks = 4 * SB_MAX;  // the any-n kernel keeps <= 8 blocks per wave in registers
     for (uint64_t i = 0; i < n_windows; ++i) {
-        REQUIRE(windows[i].site_begin <= windows[i].site_end && windows[i].site_end <= m->g.n_site,
+        REQUIRE(windows[i].site_begin <= windows[i].site_end && windows[i].site_end <= matrix_span(m),
                 "window %llu: bad site range [%llu,%llu) for %llu sites", (unsigned long long)i,
                 (unsigned long long)windows[i].site_begin, (unsigned long long)windows[i].site_end,
-                (unsigned long long)m->g.n_site);
+                (unsigned long long)matrix_span(m));
         REQUIRE(windows[i].site_end - windows[i].site_begin <= 0xFFFFFFFFull, "window %llu longer than 2^32 sites",
                 (unsigned long long)i);
     }
@@ -622,7 +622,12 @@ IMPOP_API int impop_scan_plan_create(impop_ctx *ctx, const impop_matrix *m, cons
 
     std::vector<ScanTile> tiles;
     std::vector<WinDesc> wd;
-    build_tiles(windows, n_windows, tile_blocks, wps, tiles, wd, p->bytes_streamed);
+    {
+        std::vector<impop_window> mapped;  // compacted matrix: original coordinates -> kept-site index ranges
+        map_windows(m, windows, n_windows, mapped);
+        build_tiles(mapped.data(), n_windows, tile_blocks, wps, tiles, wd, p->bytes_streamed);
+        for (uint64_t i = 0; m->compact && i < n_windows; ++i) wd[i].n_sites = windows[i].site_end - windows[i].site_begin;
+    }
     p->n_tiles = tiles.size();
     auto fail = [&](int code) {
         impop_scan_plan_destroy(p);
@@ -764,6 +769,7 @@ IMPOP_API int impop_scan(impop_ctx *ctx, const impop_matrix *m, const impop_wind
 IMPOP_API int impop_site_counts(impop_ctx *ctx, const impop_matrix *m, const uint64_t *mask, uint64_t site_begin,
                                 uint64_t site_end, uint32_t *out_host) {
     REQUIRE(ctx && m, "impop_site_counts: NULL argument");
+    NOT_COMPACT(m, "impop_site_counts");
     REQUIRE(site_begin <= site_end && site_end <= m->g.n_site, "impop_site_counts: bad site range");
     const uint64_t W = site_end - site_begin;
     if (!W) return IMPOP_OK;
@@ -803,7 +809,7 @@ IMPOP_API int impop_scan_multi(impop_ctx *ctx, const impop_matrix *m, const impo
     if (!n_windows) return IMPOP_OK;
     REQUIRE(windows && out_host, "impop_scan_multi: NULL windows/out");
     for (uint64_t i = 0; i < n_windows; ++i)
-        REQUIRE(windows[i].site_begin <= windows[i].site_end && windows[i].site_end <= m->g.n_site &&
+        REQUIRE(windows[i].site_begin <= windows[i].site_end && windows[i].site_end <= matrix_span(m) &&
                     windows[i].site_end - windows[i].site_begin <= 0xFFFFFFFFull,
                 "impop_scan_multi: window %llu: bad site range", (unsigned long long)i);
     const uint32_t n = m->g.n_hap, wps = m->g.wps, K = n_pop, NP = K * (K - 1) / 2;
@@ -825,7 +831,12 @@ IMPOP_API int impop_scan_multi(impop_ctx *ctx, const impop_matrix *m, const impo
     std::vector<ScanTile> tiles;
     std::vector<WinDesc> wd;
     uint64_t bytes = 0;
-    build_tiles(windows, n_windows, 32, wps, tiles, wd, bytes);
+    {
+        std::vector<impop_window> mapped;
+        map_windows(m, windows, n_windows, mapped);
+        build_tiles(mapped.data(), n_windows, 32, wps, tiles, wd, bytes);
+        for (uint64_t i = 0; m->compact && i < n_windows; ++i) wd[i].n_sites = windows[i].site_end - windows[i].site_begin;
+    }
     REQUIRE(tiles.size() < 0x7FFFFFFFull, "impop_scan_multi: too many tiles");
     const size_t nt = tiles.size();
     auto up = [](size_t x) { return (x + 255) / 256 * 256; };
@@ -869,6 +880,7 @@ IMPOP_API int impop_scan_multi(impop_ctx *ctx, const impop_matrix *m, const impo
 IMPOP_API int impop_afs(impop_ctx *ctx, const impop_matrix *m, const impop_window *windows, uint64_t n_windows,
                         const uint64_t *mask, uint32_t *out_host) {
     REQUIRE(ctx && m, "impop_afs: NULL argument");
+    NOT_COMPACT(m, "impop_afs");
     if (!n_windows) return IMPOP_OK;
     REQUIRE(windows && out_host, "impop_afs: NULL windows/out");
     uint64_t longest = 0;

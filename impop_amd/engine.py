@@ -270,6 +270,22 @@ class BitMatrix:
         except Exception:
             pass
 
+    def compact(self) -> "BitMatrix":
+        """A new matrix holding only the sites that are variable among all haplotypes.  Scans of it take
+        windows in THIS matrix's site coordinates and return the same records (impop_matrix_compact)."""
+        out = C.c_void_p()
+        check(self.ctx._lib.impop_matrix_compact(self.ctx.handle, self.handle, C.byref(out)))
+        bm = BitMatrix(self.ctx, out)
+        bm.compacted_from_sites = self.n_site
+        return bm
+
+    def positions(self, first: int = 0, count: Optional[int] = None) -> np.ndarray:
+        """Original site index of the kept sites of a compacted matrix."""
+        count = self.n_site - first if count is None else count
+        out = np.zeros(max(count, 0), dtype=np.uint64)
+        check(self.ctx._lib.impop_matrix_positions(self.handle, int(first), int(count), out.ctypes.data_as(C.POINTER(C.c_uint64)), None))
+        return out
+
     def download(self, site_begin: int = 0, site_end: Optional[int] = None) -> np.ndarray:
         site_end = self.n_site if site_end is None else site_end
         words = max((site_end - site_begin + 63) // 64, 1)

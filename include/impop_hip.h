@@ -93,6 +93,18 @@ int impop_matrix_synthetic(impop_ctx *ctx, uint32_t n_hap, uint64_t n_site, cons
  * (bit 0 of word 0 of each row = site_begin). */
 int impop_matrix_download(impop_ctx *ctx, const impop_matrix *m, uint64_t site_begin, uint64_t site_end,
                           uint64_t *bits_hap_major_out, uint64_t row_stride_words);
+/* Keep only the sites that are variable among ALL haplotypes (0 < c_s < n), with their original
+ * positions.  Monomorphic sites add 0 to every sum_s c(n-c) of every subset and are never segregating
+ * (what `povu gfa2vcf | wc -l` counts, run_tajd.sh:148), so impop_scan / impop_scan_plan_* /
+ * impop_scan_multi on the compacted matrix, given windows in the ORIGINAL site coordinates, return
+ * records identical to those of the full matrix (n_sites = the window's original length) while
+ * streaming only the variable sites.  Per-site outputs and the all-pairs path (impop_afs,
+ * impop_site_counts, impop_ehh, impop_pairwise_*) return IMPOP_E_UNSUPPORTED on a compacted matrix. */
+int impop_matrix_compact(impop_ctx *ctx, const impop_matrix *m, impop_matrix **out);
+/* original site index of kept sites [first, first+count) of a compacted matrix; n_site_orig (nullable)
+ * receives the original number of sites */
+int impop_matrix_positions(const impop_matrix *m, uint64_t first, uint64_t count, uint64_t *positions_out,
+                           uint64_t *n_site_orig);
 int impop_matrix_info(const impop_matrix *m, uint32_t *n_hap, uint64_t *n_site, uint64_t *device_bytes,
                       uint32_t *bytes_per_site);
 int impop_matrix_free(impop_ctx *ctx, impop_matrix *m);

@@ -563,3 +563,54 @@ def test_ehh_vs_reference_goldens_and_oracle(ctx, oracle):
     one = np.zeros(n, np.uint8); one[3] = 1
     assert bm.ehh(10, 20, one).tolist() == [500.0] * 10
     bm.free()
+
+
+def test_compacted_matrix_gives_identical_records(ctx, oracle):
+    """impop_matrix_compact keeps only the sites variable among all haplotypes; scans of it with the
+    ORIGINAL windows must return byte-identical records (n_sites, integer sums, every double), for
+    subsets, overlapping / ragged / empty windows and the K-population scan.  Per-site and all-pairs
+    entry points refuse a compacted matrix."""
+    import impop_amd
+    from impop_amd import ImpopError
+    rng = np.random.default_rng(11)
+    n, W = 93, 20000
+    anc = rng.integers(0, 2, size=W, dtype=np.uint8)
+    f = np.repeat(anc[None, :], 5, axis=0) ^ (rng.random((5, W)) < 0.01).astype(np.uint8)
+    m01 = f[rng.integers(0, 5, size=n)] ^ (rng.random((n, W)) < 0.0008).astype(np.uint8)
+    m01[:, 5000:5600] = 1  # a fixed-1 stretch and a fixed-0 stretch: whole tiles without a variable site
+    m01[:, 9000:9900] = 0
+    bm = ctx.upload_dense(m01, keep_hap_major=False)
+    cm = bm.compact()
+    c = m01.sum(axis=0)
+    var = np.nonzero((c > 0) & (c < n))[0]
+    assert cm.n_site == var.size and cm.n_hap == n
+    assert (cm.positions() == var.astype(np.uint64)).all()
+    assert (impop_amd.unpack_hap_major(cm.download(), cm.n_site) == m01[:, var]).all()
+    wins = [(0, W, W), (0, 0, 0), (17, 4999, 5000), (5000, 5600, 600), (5100, 5500, 0), (8999, 9901, 902), (9000, 9900, 900),
+            (19999, 20000, 1), (123, 19877, 50000)]
+    wins += [(s, min(s + 3000, W), 3000) for s in range(0, W, 1500)]  # overlapping (step = size / 2)
+    inA = (rng.random(n) < 0.3).astype(np.uint8)
+    inB = ((rng.random(n) < 0.4) & (inA == 0)).astype(np.uint8)
+    inP = (rng.random(n) < 0.8).astype(np.uint8)
+    for mp in (None, inP):
+        for mode, scope in ((0, 0), (1, 1), (2, 0)):
+            full = bm.scan(wins, mp, inA, inB, d_pi_mode=mode, s_scope=scope)
+            comp = cm.scan(wins, mp, inA, inB, d_pi_mode=mode, s_scope=scope)
+            assert full.tobytes() == comp.tobytes(), (mp is not None, mode, scope)
+    # one window against the oracle directly
+    r = cm.scan([(17, 4999, 5000)], None, inA, inB)[0]
+    want = oracle.window_sitecount(oracle.pack_hap_major(m01), n, 17, 4999, oracle.pack_mask(np.ones(n, np.uint8)),
+                                   oracle.pack_mask(inA), oracle.pack_mask(inB), 5000)
+    for k in ("n_sites", "s_all", "s_a", "s_b", "sum_p", "sum_a", "sum_b", "sum_ab"):
+        assert int(r[k]) == int(want[k]), k
+    for k in ("pi", "pi_site", "fst", "dxy", "tajima_d"):
+        assert rel_close(float(r[k]), float(want[k]), REL, 1e-300), k
+    pops = [np.zeros(n, np.uint8) for _ in range(3)]
+    for i in range(n):
+        pops[i % 3][i] = 1
+    assert bm.scan_multi(wins, pops).tobytes() == cm.scan_multi(wins, pops).tobytes()
+    for call in (lambda: cm.afs(wins[:2]), lambda: cm.site_counts(0, 10), lambda: cm.ehh(0, 10), lambda: cm.compact()):
+        with pytest.raises(ImpopError):
+            call()
+    cm.free()
+    bm.free()

@@ -65,6 +65,8 @@ def main():
     ap.add_argument("-p", "--region-prefix", default="CHM13#0#")
     ap.add_argument("-o", "--output")
     ap.add_argument("--identity", choices=["match", "dice"], default="match")
+    ap.add_argument("--compact", action="store_true", help="scan from the matrix compacted to its variable sites "
+                    "(impop_matrix_compact): identical output, far fewer bytes per pass; not for thresholded pica2")
     ap.add_argument("--device", type=int, default=None, help="default: LOCAL_RANK, else 0")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend when launched with WORLD_SIZE > 1 "
                     "(nccl = RCCL over xGMI; gloo for rehearsals)")
@@ -113,6 +115,13 @@ def main():
         wins = [(int(w["site_begin"]), int(w["site_end"]), int(w["seq_len"])) for w in loc]
     else:
         bm = ctx.upload(mf.bits, mf.n_site, keep_hap_major=need_pairwise)
+    if args.compact:
+        if need_pairwise:
+            print("Error: --compact cannot be combined with thresholded / rounded pica2 (all-pairs path)", file=sys.stderr)
+            sys.exit(2)
+        full = bm
+        bm = full.compact()
+        full.free()
     mask_p = mask_a = mask_b = None
     sample_count = mf.n_hap
     if args.sample_list:

@@ -56,6 +56,12 @@ def test_batch_driver_tables(tmp_path, oracle):
         # D is printed with repr(); n = 12 list lines (run_tajd.sh:83) => recompute through the oracle
         D, _ = oracle.tajimas_d(n, float(w["s_all"]), oracle.py_round(w["pi_site"], 8))
         assert abs(float(t[5]) - D) <= 1e-9 * abs(D)
+    # --compact: the same tables from the matrix compacted to its variable sites
+    rc = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "impop_scan.py"), "--matrix", str(tmp_path / "m.npz"),
+                         "--bed", str(tmp_path / "w.bed"), "--format", "all", "-A", str(tmp_path / "A.txt"), "-B", str(tmp_path / "B.txt"),
+                         "-l", str(tmp_path / "all.txt"), "--compact"], capture_output=True, text=True)
+    assert rc.returncode == 0, rc.stderr
+    assert rc.stdout == r.stdout
     # 3 x pi table (run_fst_impg.sh): PI_C = pica2 on the union list, here against the oracle's pica2
     r3 = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "impop_scan.py"), "--matrix", str(tmp_path / "m.npz"),
                          "--bed", str(tmp_path / "w.bed"), "--format", "fst3pi", "-A", str(tmp_path / "A.txt"), "-B", str(tmp_path / "B.txt")],

@@ -614,3 +614,26 @@ def test_compacted_matrix_gives_identical_records(ctx, oracle):
             call()
     cm.free()
     bm.free()
+
+
+def test_int8_gram_kernel_still_exact():
+    """The int8 + look-up-table Gram kernel is kept for A/B measurements (IMPOP_GRAM_MFMA=i8; the FP4
+    bit-plane kernel is the default).  The switch is read once per process, hence the subprocess."""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    code = (
+        "import numpy as np, impop_amd\n"
+        "ctx = impop_amd.Context(0)\n"
+        "rng = np.random.default_rng(3)\n"
+        "m = (rng.random((131, 3000)) < 0.3).astype(np.uint8)\n"
+        "bm = ctx.upload_dense(m, keep_hap_major=True)\n"
+        "for s0, s1 in ((0, 3000), (17, 2049), (64, 128), (5, 6)):\n"
+        "    I = bm.pairwise_counts(s0, s1).astype(np.int64)\n"
+        "    w = m[:, s0:s1].astype(np.int64)\n"
+        "    assert (I == w @ w.T).all(), (s0, s1)\n"
+        "print('ok')\n")
+    env = dict(os.environ, IMPOP_GRAM_MFMA="i8", PYTHONPATH=ROOT)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, cwd=ROOT)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stderr

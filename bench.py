@@ -66,6 +66,53 @@ def host_cores():
     return max(min(n, 16), 1)
 
 
+def secondary_points(ctx, bm, windows, in_a, in_b, ref_records):
+    """Secondary measurements reported NEXT TO the headline (never folded into `value`): SURVEY §8(d)'s
+    "W = S-only" point (the same windows scanned from the matrix compacted to its variable sites, records
+    byte-identical) and the all-pairs (Gram, MFMA-bound) mode of the same window shape."""
+    import numpy as np
+
+    import impop_amd
+    out = {}
+    try:
+        t0 = time.perf_counter()
+        cm = bm.compact()
+        ctx.synchronize()
+        t_c = time.perf_counter() - t0
+        plan = cm.plan(windows, None, in_a, in_b)
+        plan.launch(); ctx.synchronize()
+        plan.timing(True)
+        for _ in range(20):
+            plan.launch()
+        ms, k = plan.elapsed()
+        same = plan.fetch().tobytes() == ref_records.tobytes()
+        out["variable_sites_only"] = {"windows_per_s_kernel": len(windows) / (ms / k / 1e3), "kernel_ms": ms / k,
+                                      "variable_sites": cm.n_site, "of_sites": bm.n_site, "compaction_s": t_c,
+                                      "layout_GBps": plan.bytes_streamed / (ms / k / 1e3) / 1e9,
+                                      "records_identical_to_full_matrix": bool(same)}
+        plan.destroy(); cm.free()
+    except Exception as e:  # a secondary point must not take the headline line down; the error is reported
+        out["variable_sites_only"] = {"error": repr(e)}
+    try:
+        n, W = bm.n_hap, int(windows[0]["site_end"]) - int(windows[0]["site_begin"])
+        NWp = 1024
+        pm = ctx.synthetic(n, W * NWp, seed=20251031, keep_hap_major=True)
+        pw = impop_amd.fixed_windows(W * NWp, W)
+        pm.pairwise_scan(pw[:64], None, in_a, in_b, kind="match", threshold=0.999, round_digits=5)
+        ctx.synchronize()
+        t0 = time.perf_counter()
+        pm.pairwise_scan(pw, None, in_a, in_b, kind="match", threshold=0.999, round_digits=5)
+        dt = time.perf_counter() - t0
+        macs = n * (n + 1) // 2 * W
+        out["all_pairs_mode"] = {"windows_per_s": NWp / dt, "windows": NWp, "what": "scan for S + FP4-MFMA Gram + pica2 (-t 0.999 -r 5) "
+                                 "+ h-fst + D per window, incl. plan build and copies", "bound": "mfma",
+                                 "algorithmic_macs_per_window": macs, "frac_of_fp4_dense_peak": macs * NWp / dt / 5.0e15}
+        pm.free()
+    except Exception as e:
+        out["all_pairs_mode"] = {"error": repr(e)}
+    return out
+
+
 def cpu_baseline(bm, windows, in_a, in_b, budget_s=12.0):
     """Time the CPU oracle (oracle/impop_oracle.c, the restated reference algorithm: all-pairs
     Hamming -> identity -> pica2/h-fst/tj_d) on a bounded sample of the SAME windows, one host
@@ -287,8 +334,10 @@ def main():
         dist.all_reduce(k, op=dist.ReduceOp.MAX)
         kern_ms = float(k.item())
 
+    secondary = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu, first = cpu_baseline(bm, windows, in_a, in_b)
+        secondary = secondary_points(ctx, bm, windows, in_a, in_b, recs)
 
     if rank == 0:
         total_windows = NW * world * args.steps
@@ -313,6 +362,7 @@ def main():
                          "algorithmic_bytes_per_launch": algo_bytes, "layout_bytes_per_launch": plan.bytes_streamed,
                          "layout_GBps": plan.bytes_streamed / avg_kern_s / 1e9},
             "cpu_baseline": cpu,
+            "secondary": secondary,
         }
         print(json.dumps(out), flush=True)
     plan.destroy()

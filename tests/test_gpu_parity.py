@@ -637,3 +637,26 @@ def test_int8_gram_kernel_still_exact():
     env = dict(os.environ, IMPOP_GRAM_MFMA="i8", PYTHONPATH=ROOT)
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, cwd=ROOT)
     assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stderr
+
+
+def test_gram_exact_beyond_fp32_integer_range(ctx):
+    """FP4 MFMAs accumulate in fp32, exact only below 2^24: a window longer than that is K-split so
+    that every partial stays exact and the int32 sum is still I_ij to the last unit (all-ones rows:
+    I_ij = W = 2^25 + 77; a second matrix with every third site set in half of the rows)."""
+    W = (1 << 25) + 77
+    words = (W + 63) // 64
+    n = 40
+    bits = np.full((n, words), np.uint64(0xFFFFFFFFFFFFFFFF), dtype=np.uint64)
+    bm = ctx.upload(bits, W, keep_hap_major=True)
+    I = bm.pairwise_counts(0, W)
+    assert (I == W).all()
+    I2 = bm.pairwise_counts(3, W - 5)
+    assert (I2 == W - 8).all()
+    bm.free()
+    pat = np.uint64(0x9249249249249249)  # bits 0, 3, 6, ... of the word; period 3 does not divide 64, so use counts
+    bits[::2] = pat
+    bm = ctx.upload(bits, W, keep_hap_major=True)
+    I = bm.pairwise_counts(0, W)
+    a = int(np.unpackbits(bits[0].view(np.uint8), bitorder="little")[:W].sum())
+    assert int(I[0, 0]) == a and int(I[0, 2]) == a and int(I[0, 1]) == a and int(I[1, 1]) == W and int(I[1, 3]) == W
+    bm.free()

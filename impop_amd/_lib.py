@@ -57,7 +57,7 @@ class PairStats(C.Structure):
 class PairwiseParams(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("identity_kind", C.c_int32), ("threshold", C.c_double),
                 ("round_digits", C.c_int32), ("d_pi_mode", C.c_int32), ("s_scope", C.c_int32),
-                ("reserved", C.c_uint32)]
+                ("fst_method", C.c_uint32)]
 
 
 class PairwiseStats(C.Structure):

@@ -706,6 +706,7 @@ IMPOP_API int impop_pairwise_scan(impop_ctx *ctx, const impop_matrix *m, const i
     REQUIRE(params->round_digits <= 19, "impop_pairwise_scan: round_digits > 19 unsupported");
     REQUIRE(params->d_pi_mode >= 0 && params->d_pi_mode <= 2 && (params->s_scope == 0 || params->s_scope == 1),
             "impop_pairwise_scan: bad d_pi_mode / s_scope");
+    REQUIRE(params->fst_method <= 1, "impop_pairwise_scan: fst_method must be 0 (direct) or 1 (grouped)");
     if (!n_windows) return IMPOP_OK;
     REQUIRE(windows && out_host, "impop_pairwise_scan: NULL windows/out");
     for (uint64_t i = 0; i < n_windows; ++i) {
@@ -734,6 +735,11 @@ IMPOP_API int impop_pairwise_scan(impop_ctx *ctx, const impop_matrix *m, const i
         fb[i] = mask_b ? (uint8_t)((mask_b[i >> 6] >> (i & 63)) & 1ull) : 0;
     }
     const uint32_t nP = (uint32_t)idx.size();
+    std::vector<uint32_t> ia, ib;  // hud.py grouped: members of A / B with the overlap removed from both
+    for (uint32_t i = 0; i < n && params->fst_method == 1; ++i) {
+        if (fa[i] && !fb[i]) ia.push_back(i);
+        if (fb[i] && !fa[i]) ib.push_back(i);
+    }
     // windows are processed in chunks so the Gram scratch stays bounded (<= ~4 GiB of 288): large chunks keep
     // the persistent Gram grid's last, partially filled round of tasks small next to the whole launch
     const size_t gram_bytes = (size_t)ld * ld * 4;
@@ -744,7 +750,7 @@ IMPOP_API int impop_pairwise_scan(impop_ctx *ctx, const impop_matrix *m, const i
     void *d = nullptr;
     const size_t need = 4096 + chunk * (gram_bytes + sizeof(GramWindow) + 16 + sizeof(Pica2Out) + sizeof(HfstOut) +
                                         sizeof(impop_window_stats) + sizeof(impop_pairwise_stats) + 2048) +
-                        (size_t)n * 8 + 4096;
+                        (size_t)n * 16 + 8192;
     rc = ctx_scratch(ctx, need, &d);
     if (rc) return fail(rc);
     Carve2 cv(d);
@@ -759,12 +765,16 @@ IMPOP_API int impop_pairwise_scan(impop_ctx *ctx, const impop_matrix *m, const i
     uint32_t *d_idx = cv.take<uint32_t>(n ? n : 1);
     uint8_t *d_fa = cv.take<uint8_t>(n ? n : 1);
     uint8_t *d_fb = cv.take<uint8_t>(n ? n : 1);
+    uint32_t *d_ia = cv.take<uint32_t>(n ? n : 1);
+    uint32_t *d_ib = cv.take<uint32_t>(n ? n : 1);
     hipError_t e;
 #define PW_TRY(expr) \
     if ((e = (expr)) != hipSuccess) return fail(hip_fail(e, #expr, __FILE__, __LINE__))
     if (nP) PW_TRY(hipMemcpyAsync(d_idx, idx.data(), (size_t)nP * 4, hipMemcpyHostToDevice, ctx->stream));
     PW_TRY(hipMemcpyAsync(d_fa, fa.data(), n, hipMemcpyHostToDevice, ctx->stream));
     PW_TRY(hipMemcpyAsync(d_fb, fb.data(), n, hipMemcpyHostToDevice, ctx->stream));
+    if (!ia.empty()) PW_TRY(hipMemcpyAsync(d_ia, ia.data(), ia.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    if (!ib.empty()) PW_TRY(hipMemcpyAsync(d_ib, ib.data(), ib.size() * 4, hipMemcpyHostToDevice, ctx->stream));
     rc = impop_scan_plan_launch(plan, nullptr);
     if (rc) return fail(rc);
     std::vector<impop_window_stats> scan_host(n_windows);
@@ -793,7 +803,10 @@ IMPOP_API int impop_pairwise_scan(impop_ctx *ctx, const impop_matrix *m, const i
         b.round_digits = params->round_digits < 0 ? -1 : params->round_digits;
         rc = launch_pica2(ctx, b, cnt, mask_p ? d_idx : nullptr, nP, params->threshold, d_L, d_p, nullptr);
         if (rc) return fail(rc);
-        rc = launch_hfst(ctx, b, cnt, d_fa, d_fb, d_L, d_h);
+        if (params->fst_method == 1)
+            rc = launch_hud_grouped(ctx, b, cnt, d_ia, (uint32_t)ia.size(), d_ib, (uint32_t)ib.size(), params->threshold, d_L, d_h);
+        else
+            rc = launch_hfst(ctx, b, cnt, d_fa, d_fb, d_L, d_h);
         if (rc) return fail(rc);
         PairFinalIn in{d_p, d_h, d_s};
         rc = ensure_tajima_consts(ctx, nP >= 2 ? (int64_t)nP : 2);  // the cache may have been retargeted by another plan

@@ -402,6 +402,20 @@ int launch_hfst(impop_ctx *ctx, const SimBatch &b, uint64_t n_problems, const ui
     return IMPOP_OK;
 }
 
+int launch_hud_grouped(impop_ctx *ctx, const SimBatch &b, uint64_t n_problems, const uint32_t *d_ia, uint32_t ma,
+                       const uint32_t *d_ib, uint32_t mb, double threshold, const uint64_t *d_seq_len, HfstOut *d_out) {
+    if (!n_problems) return IMPOP_OK;
+    REQUIRE(n_problems < 0x7FFFFFFFull, "grouped Fst: too many problems");
+    const size_t lds = (size_t)std::max(ma, mb) * 8 + ((size_t)ma + mb) * 8 + 16;
+    REQUIRE(lds <= 150 * 1024, "grouped Fst: populations too large for the LDS-resident grouping");
+    if (lds > 48 * 1024)
+        HIP_TRY(hipFuncSetAttribute((const void *)hud_grouped_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(hud_grouped_kernel, dim3((uint32_t)n_problems), dim3(ST), lds, ctx->stream, b, d_ia, ma, d_ib, mb, threshold,
+                       d_seq_len, d_out);
+    HIP_TRY(hipGetLastError());
+    return IMPOP_OK;
+}
+
 int launch_af(impop_ctx *ctx, const SimBatch &b, double threshold, uint32_t *d_adj, uint32_t *d_cluster_of,
               uint32_t *d_sizes, uint32_t *d_nclusters) {
     const uint32_t n = b.n, words = (n + 31) / 32;
@@ -635,10 +649,8 @@ IMPOP_API int impop_fst_grouped_from_identity(impop_ctx *ctx, const double *iden
     HIP_TRY(hipMemcpyAsync(d_L, &seq_len, 8, hipMemcpyHostToDevice, ctx->stream));
     SimBatch b{};
     b.dense = d_id; b.stride = nn; b.ld = n; b.n = n; b.round_digits = round_digits < 0 ? -1 : round_digits;
-    if (lds > 48 * 1024)
-        HIP_TRY(hipFuncSetAttribute((const void *)hud_grouped_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(hud_grouped_kernel, dim3(1), dim3(ST), lds, ctx->stream, b, d_ia, ma, d_ib, mb, threshold, d_L, d_out);
-    HIP_TRY(hipGetLastError());
+    rc = launch_hud_grouped(ctx, b, 1, d_ia, ma, d_ib, mb, threshold, d_L, d_out);
+    if (rc) return rc;
     HfstOut o;
     HIP_TRY(hipMemcpyAsync(&o, d_out, sizeof o, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));  // ia / ib (pageable) must outlive the copies

@@ -104,6 +104,9 @@ int launch_pica2(impop_ctx *ctx, const SimBatch &b, uint64_t n_problems, const u
                  double threshold, const uint64_t *d_seq_len, Pica2Out *d_out, uint32_t *d_group_of);
 int launch_hfst(impop_ctx *ctx, const SimBatch &b, uint64_t n_problems, const uint8_t *d_in_a, const uint8_t *d_in_b,
                 const uint64_t *d_seq_len, HfstOut *d_out);
+// hud.py grouped Fst: members of A / B as index lists (overlap already removed)
+int launch_hud_grouped(impop_ctx *ctx, const SimBatch &b, uint64_t n_problems, const uint32_t *d_ia, uint32_t ma,
+                       const uint32_t *d_ib, uint32_t mb, double threshold, const uint64_t *d_seq_len, HfstOut *d_out);
 int launch_af(impop_ctx *ctx, const SimBatch &b, double threshold, uint32_t *d_adj, uint32_t *d_cluster_of,
               uint32_t *d_sizes, uint32_t *d_nclusters);
 

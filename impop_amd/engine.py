@@ -358,12 +358,15 @@ class BitMatrix:
         return out
 
     def pairwise_scan(self, windows, mask_p=None, mask_a=None, mask_b=None, kind: str = "match", threshold: float = 0.99,
-                      round_digits: Optional[int] = None, d_pi_mode: int = 0, s_scope: int = 0) -> np.ndarray:
-        """Full pica2 / h-fst semantics (threshold grouping, rounding) per window from the bit matrix."""
+                      round_digits: Optional[int] = None, d_pi_mode: int = 0, s_scope: int = 0,
+                      fst_method: str = "direct") -> np.ndarray:
+        """Full pica2 / h-fst semantics (threshold grouping, rounding) per window from the bit matrix;
+        fst_method='grouped' switches the Fst fields to hud.py's grouped method at the same threshold."""
         w = make_windows(windows)
         out = np.zeros(len(w), dtype=PAIRWISE_DTYPE)
         prm = PairwiseParams(C.sizeof(PairwiseParams), IDENTITY_KINDS[kind], float(threshold),
-                             -1 if round_digits is None else int(round_digits), int(d_pi_mode), int(s_scope), 0)
+                             -1 if round_digits is None else int(round_digits), int(d_pi_mode), int(s_scope),
+                             {"direct": 0, "grouped": 1}[fst_method])
         kp, pp = _mask_ptr(mask_p, self.n_hap)
         ka, pa = _mask_ptr(mask_a, self.n_hap)
         kb, pb = _mask_ptr(mask_b, self.n_hap)

@@ -230,7 +230,7 @@ typedef struct impop_pairwise_params {
     int32_t round_digits;    /* pica2 -r / h-fst -r; < 0 = none */
     int32_t d_pi_mode;       /* as impop_scan_params */
     int32_t s_scope;
-    uint32_t reserved;
+    uint32_t fst_method;     /* 0 = h-fst.py / hud.py direct; 1 = hud.py -m grouped at `threshold` (hud.py:64-128, 235-263) */
 } impop_pairwise_params;
 typedef struct impop_pairwise_stats { /* 96 bytes */
     double pi, pi_site;                      /* pica2.py:154,164 on subset P with grouping */

@@ -65,6 +65,8 @@ def main():
     ap.add_argument("-p", "--region-prefix", default="CHM13#0#")
     ap.add_argument("-o", "--output")
     ap.add_argument("--identity", choices=["match", "dice"], default="match")
+    ap.add_argument("--fst-method", choices=["direct", "grouped"], default="direct",
+                    help="hfst: grouped = scripts/hudson/hud.py -m grouped at -t (default 0.999), per window on the all-pairs path")
     ap.add_argument("--compact", action="store_true", help="scan from the matrix compacted to its variable sites "
                     "(impop_matrix_compact): identical output, far fewer bytes per pass; not for thresholded pica2")
     ap.add_argument("--device", type=int, default=None, help="default: LOCAL_RANK, else 0")
@@ -99,8 +101,9 @@ def main():
         regions.append(region)
     out = (open(args.output, "w") if args.output else sys.stdout) if rank == 0 else open(os.devnull, "w")
     ctx = impop_amd.Context(args.device)
-    need_pairwise = args.format == "pica2" and ((args.threshold is not None and args.threshold < 1.0) or args.round_digits is not None
-                                                 or args.identity != "match")
+    grouped_fst = args.format == "hfst" and args.fst_method == "grouped"
+    need_pairwise = grouped_fst or (args.format == "pica2" and ((args.threshold is not None and args.threshold < 1.0)
+                                                                 or args.round_digits is not None or args.identity != "match"))
     all_wins = impop_amd.make_windows(wins)
     if world > 1:
         from impop_amd.distributed import shard_windows
@@ -157,8 +160,10 @@ def main():
         ctx.close()
         return
     if need_pairwise:
-        thr = 0.99 if args.threshold is None else args.threshold  # pica2.py:175 CLI default
-        res = bm.pairwise_scan(wins, mask_p, mask_a, mask_b, kind=args.identity, threshold=thr, round_digits=args.round_digits)
+        # CLI defaults of the reference: pica2.py:175 (-t 0.99), hud.py -t 0.999
+        thr = (0.999 if grouped_fst else 0.99) if args.threshold is None else args.threshold
+        res = bm.pairwise_scan(wins, mask_p, mask_a, mask_b, kind=args.identity, threshold=thr, round_digits=args.round_digits,
+                               fst_method=args.fst_method if grouped_fst else "direct")
     else:
         res = bm.scan(wins, mask_p, mask_a, mask_b)
     if world > 1:

@@ -89,6 +89,37 @@ def test_batch_driver_tables(tmp_path, oracle):
         assert l2[1 + k] == f"{reg}\t{L}\t0.995\t4\t{ps:.8f} (sequence length: {L})"
 
 
+def test_batch_driver_grouped_fst(tmp_path, oracle):
+    """--format hfst --fst-method grouped: hud.py's grouped Fst per BED row (oracle_hud_grouped on the
+    oracle's identity of the window)."""
+    from impop_amd import matrixio
+    rng = np.random.default_rng(5)
+    n, W = 20, 3000
+    anc = rng.integers(0, 2, size=W, dtype=np.uint8)
+    f = np.repeat(anc[None], 3, axis=0) ^ (rng.random((3, W)) < 0.02).astype(np.uint8)
+    m = f[rng.integers(0, 3, size=n)] ^ (rng.random((n, W)) < 0.001).astype(np.uint8)
+    names = [f"S{i // 2:03d}#{i % 2 + 1}#chr9:0-{W}" for i in range(n)]
+    matrixio.save_matrix(str(tmp_path / "m.npz"), matrixio.from_dense(m, names, origin=0, contig="CHM13#0#chr9"))
+    (tmp_path / "w.bed").write_text("chr9\t0\t1500\nchr9\t1000\t3000\n")
+    (tmp_path / "A.txt").write_text("S000\nS001\nS002\nS003\n")
+    (tmp_path / "B.txt").write_text("S005\nS006\nS007\nS008\nS009\n")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "impop_scan.py"), "--matrix", str(tmp_path / "m.npz"),
+                        "--bed", str(tmp_path / "w.bed"), "--format", "hfst", "--fst-method", "grouped", "-t", "0.995",
+                        "-A", str(tmp_path / "A.txt"), "-B", str(tmp_path / "B.txt")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    lines = r.stdout.strip().split("\n")
+    assert lines[0] == "REGION\tLENGTH\tFST\tPI_A\tPI_B\tPI_XY\tDXY\tDA"
+    inA = np.array([1 if int(nm[1:4]) <= 3 else 0 for nm in names], np.uint8)
+    inB = np.array([1 if 5 <= int(nm[1:4]) <= 9 else 0 for nm in names], np.uint8)
+    bits = oracle.pack_hap_major(m)
+    for k, (s0, s1) in enumerate(((0, 1500), (1000, 3000))):
+        sim = oracle.identity(oracle.pairwise_counts(bits, n, s0, s1), s1 - s0, 0)
+        want, _ = oracle.hud_grouped(sim, inA, inB, 0.995, s1 - s0, None)
+        h = lines[1 + k].split("\t")
+        for got, key in zip(h[2:], ("fst", "pi_a", "pi_b", "pi_xy", "dxy", "da")):
+            assert abs(float(got) - want[key]) <= 1.0000001e-8, (key, got, want[key])
+
+
 def test_batch_driver_two_ranks_equal_one(tmp_path):
     """The driver sharded over 2 ranks (gloo rehearsal: both ranks share the one GPU of the test
     box; on a node it is one rank per GPU over RCCL) prints exactly what 1 rank prints."""

@@ -660,3 +660,33 @@ def test_gram_exact_beyond_fp32_integer_range(ctx):
     a = int(np.unpackbits(bits[0].view(np.uint8), bitorder="little")[:W].sum())
     assert int(I[0, 0]) == a and int(I[0, 2]) == a and int(I[0, 1]) == a and int(I[1, 1]) == W and int(I[1, 3]) == W
     bm.free()
+
+
+def test_pairwise_scan_grouped_fst(ctx, oracle):
+    """impop_pairwise_scan with fst_method='grouped': hud.py's grouped Fst (oracle_hud_grouped, pinned by
+    goldens from the real hud.py) per window on identities formed from the Gram counts; the pica2 /
+    Tajima fields must not change with the Fst method."""
+    rng = np.random.default_rng(21)
+    n, W = 57, 2600
+    anc = rng.integers(0, 2, size=W, dtype=np.uint8)
+    f = np.repeat(anc[None, :], 4, axis=0) ^ (rng.random((4, W)) < 0.02).astype(np.uint8)
+    m01 = f[rng.integers(0, 4, size=n)] ^ (rng.random((n, W)) < 0.0006).astype(np.uint8)
+    bits = oracle.pack_hap_major(m01)
+    bm = ctx.upload_dense(m01, keep_hap_major=True)
+    inA = (rng.random(n) < 0.45).astype(np.uint8)
+    inB = (rng.random(n) < 0.45).astype(np.uint8)  # overlaps A on purpose (hud.py:186-190)
+    wins = [(0, W, W), (100, 1400, 5000), (64, 128, 64), (1999, 2600, 0)]
+    for kind, kid in (("match", 0), ("dice", 1)):
+        for thr, rd in ((0.999, None), (0.99, 3), (1.0, None), (0.9985, 4)):
+            direct = bm.pairwise_scan(wins, None, inA, inB, kind=kind, threshold=thr, round_digits=rd)
+            got = bm.pairwise_scan(wins, None, inA, inB, kind=kind, threshold=thr, round_digits=rd, fst_method="grouped")
+            for (s0, s1, L), r, d in zip(wins, got, direct):
+                sim = oracle.identity(oracle.pairwise_counts(bits, n, s0, s1), s1 - s0, kid)
+                want, _ = oracle.hud_grouped(sim, inA, inB, thr, L if L else None, rd)
+                for k in ("fst", "pi_a", "pi_b", "pi_xy", "dxy", "da"):
+                    assert rel_close(float(r[k]), want[k], REL, 1e-300), (kind, thr, rd, (s0, s1), k, float(r[k]), want[k])
+                for k in ("pi", "pi_site", "tajima_d"):
+                    a, b = float(r[k]), float(d[k])
+                    assert a == b or (a != a and b != b), k
+                assert int(r["n_groups"]) == int(d["n_groups"])
+    bm.free()

@@ -199,7 +199,17 @@ def main():
                      run([os.path.join(sc, "tj_d.py"), "-n", "10", "-p", "0.1", "-S", "0"])],
             "af": [run([os.path.join(sc, "af.py"), "--input", p, "--threshold", "0.999"]),
                    run([os.path.join(sc, "af.py"), "--input", p, "--threshold", "0.9996"])],
+            # the three invocations of scripts/hudson/example_fst_methods.py:47-58 (its `fst.py` is hud.py);
+            # inside both populations every identity is > 0.999, so the grouping does not depend on set order
+            "hud": [run([os.path.join(sc, "hudson", "hud.py"), p, "-a", pa, "-b", pb, "-l", "1000000", "-d", td] + extra)
+                    for extra in (["-m", "direct"], ["-m", "grouped", "-t", "0.999"], ["-m", "grouped", "-t", "0.996"])],
         }
+        # library-level values of the same three calls
+        six["hud"] = []
+        hd2, _ = hud.read_similarity_file(p)
+        for method, thr in (("direct", 0.999), ("grouped", 0.999), ("grouped", 0.996)):
+            r = hud.calculate_fst(hd2, set(A), set(B), 1000000, None, None, method, thr)
+            six["hud"].append({"method": method, "threshold": hx(thr), "L": 1000000, "out": {k: hx(v) for k, v in r.items()}})
     json.dump({"meta": meta, **six}, open(os.path.join(args.out, "six_seq.json"), "w"), indent=1)
 
     # ------------------------------------------ population-name expansion (a6)

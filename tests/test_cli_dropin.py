@@ -44,7 +44,7 @@ def test_six_sequence_cli(tmp_path):
             f.write(f"{a}\t{b}\t{fh(v)!r}\n")
     open(os.path.join(td, "pop_A.txt"), "w").write("seq1_popA\nseq2_popA\nseq3_popA\n")
     open(os.path.join(td, "pop_B.txt"), "w").write("seq4_popB\nseq5_popB\nseq6_popB\n")
-    for script, key in (("pica2.py", "pica2"), ("h-fst.py", "hfst"), ("tj_d.py", "tj_d"), ("af.py", "af")):
+    for script, key in (("pica2.py", "pica2"), ("h-fst.py", "hfst"), ("tj_d.py", "tj_d"), ("af.py", "af"), ("hud.py", "hud")):
         for c in g["cli"][key]:
             r = run(script, remap(c["argv"], td), td)
             assert r.returncode == c["rc"], (script, c["argv"], r.stderr)

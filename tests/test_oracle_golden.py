@@ -83,6 +83,14 @@ def test_six_sequence_table(oracle):
         out, _ = oracle.hfst(sim, inA, inB, c["L"], c["round"])
         for k, v in c["out"].items():
             assert rel_close(out[k], fh(v), TOL), (k, out[k], fh(v))
+    # the three calls of scripts/hudson/example_fst_methods.py:47-58 (direct, grouped 0.999, grouped 0.996)
+    for c in g["hud"]:
+        if c["method"] == "grouped":
+            out, _ = oracle.hud_grouped(sim, inA, inB, fh(c["threshold"]), c["L"], None)
+        else:
+            out, _ = oracle.hfst(sim, inA, inB, c["L"], None)
+        for k, v in c["out"].items():
+            assert rel_close(out[k], fh(v), TOL), (c["method"], k, out[k], fh(v))
     for c in g["af"]:
         np.fill_diagonal(sim, np.nan)  # the table has no self rows
         cl, K, sz = oracle.af_cluster(sim, fh(c["threshold"]))

@@ -96,9 +96,18 @@ struct LaneAcc {
     uint64_t q_p = 0, q_a = 0, q_b = 0, q_ab = 0;
 };
 
+// Fixed-WPS kernel (n <= 512): every product c (n - c) is below 2^16, so the lane accumulators of one
+// tile fit 32 bits (<= 1024 sites per lane and tile) and the multiply is a 24-bit v_mul / v_mad
+// (v_mul_lo_u32 is a quarter-rate instruction); they are widened once, at the tile reduction.  This is
+// what lifts the small-n cases, which are VALU-bound rather than HBM-bound (4-16 B per site).
+struct LaneAcc32 {
+    uint32_t s_all = 0, s_p = 0, s_a = 0, s_b = 0;
+    uint32_t q_p = 0, q_a = 0, q_b = 0, q_ab = 0;
+};
+
 template <int WPS, bool SUBSET_P>
 __device__ __forceinline__ void site_accumulate(const uint32_t (&w)[WPS], const MaskArgs<WPS> &mk, const PopSizes &ps,
-                                                bool valid, LaneAcc &acc) {
+                                                bool valid, LaneAcc32 &acc) {
     uint32_t c = 0, cP = 0, cA = 0, cB = 0;
 #pragma unroll
     for (int k = 0; k < WPS; ++k) {
@@ -113,10 +122,10 @@ __device__ __forceinline__ void site_accumulate(const uint32_t (&w)[WPS], const 
         acc.s_p += (cP != 0 && cP != ps.nP);
         acc.s_a += (cA != 0 && cA != ps.nA);
         acc.s_b += (cB != 0 && cB != ps.nB);
-        acc.q_p += cP * (ps.nP - cP);
-        acc.q_a += cA * (ps.nA - cA);
-        acc.q_b += cB * (ps.nB - cB);
-        acc.q_ab += cA * (ps.nB - cB) + cB * (ps.nA - cA);
+        acc.q_p += __umul24(cP, ps.nP - cP);
+        acc.q_a += __umul24(cA, ps.nA - cA);
+        acc.q_b += __umul24(cB, ps.nB - cB);
+        acc.q_ab += __umul24(cA, ps.nB - cB) + __umul24(cB, ps.nA - cA);
     }
 }
 
@@ -157,7 +166,7 @@ __global__ __launch_bounds__(256, IMPOP_SCAN_MIN_WAVES) void scan_tiles_kernel(c
     const uint64_t b0 = t.site_begin >> 6, b1 = (t.site_end + 63) >> 6;
     // wave index through readfirstlane: block addresses and the loop stay scalar (SGPR) state
     const uint32_t lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    LaneAcc acc;
+    LaneAcc32 acc;
     uint64_t b = b0 + wave;
     constexpr int G = (WPS + 3) / 4;
     constexpr int U = IMPOP_SCAN_UNROLL > 0 ? IMPOP_SCAN_UNROLL : (G >= 3 ? 2 : G == 2 ? 4 : 8);
@@ -178,7 +187,10 @@ __global__ __launch_bounds__(256, IMPOP_SCAN_MIN_WAVES) void scan_tiles_kernel(c
         const uint64_t s0 = b * 64 + lane;
         site_accumulate<WPS, SUBSET_P>(w0, mk, ps, s0 >= t.site_begin && s0 < t.site_end, acc);
     }
-    tile_reduce_store(acc, out);
+    LaneAcc wide;
+    wide.s_all = acc.s_all; wide.s_p = acc.s_p; wide.s_a = acc.s_a; wide.s_b = acc.s_b;
+    wide.q_p = acc.q_p; wide.q_a = acc.q_a; wide.q_b = acc.q_b; wide.q_ab = acc.q_ab;
+    tile_reduce_store(wide, out);
 }
 
 // Any wps (n > 512 haplotypes): the haplotype axis is walked in chunks of 16 dwords whose three

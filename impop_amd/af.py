@@ -8,20 +8,17 @@ import numpy as np
 from .runtime import default_context
 
 
+def _sample_of(name: str) -> str:
+    return name.split(":", 1)[0]  # the PanSN name without its `:start-end` range
+
+
 def load_pairs(path):
-    """af.load_pairs (af.py:7-19): names are cut at the first ':'."""
-    rows = []
-    samples = set()
-    with open(path) as f:
-        reader = csv.DictReader(f, delimiter="\t")
-        for row in reader:
-            a = row["group.a"].split(":", 1)[0]
-            b = row["group.b"].split(":", 1)[0]
-            val = float(row["estimated.identity"])
-            rows.append((a, b, val))
-            samples.add(a)
-            samples.add(b)
-    return rows, sorted(samples)
+    """-> ([(sample_a, sample_b, identity), ...] in file order, sorted sample names); like af.load_pairs
+    (af.py:7-19) a missing column is a KeyError and a bad number a ValueError."""
+    with open(path) as handle:
+        triples = [(_sample_of(rec["group.a"]), _sample_of(rec["group.b"]), float(rec["estimated.identity"]))
+                   for rec in csv.DictReader(handle, delimiter="\t")]
+    return triples, sorted({t[0] for t in triples} | {t[1] for t in triples})
 
 
 def cluster(rows, samples, threshold, ctx=None):
@@ -51,27 +48,22 @@ def cluster(rows, samples, threshold, ctx=None):
 
 
 def build_summary(clusters):
-    """af.build_summary (af.py:46-54)"""
-    total = sum(len(c) for c in clusters)
-    summary = []
-    for idx, members in enumerate(clusters, 1):
-        count = len(members)
-        freq = (count / total) if total else 0.0
-        summary.append((f"c{idx}", count, freq, sorted(members)))
-    return summary
+    """-> [(cluster id c1.., size, frequency, sorted members)] in the given order (af.py:46-54)"""
+    sizes = [len(c) for c in clusters]
+    total = sum(sizes)
+    return [(f"c{k}", size, (size / total if total else 0.0), sorted(members))
+            for k, (members, size) in enumerate(zip(clusters, sizes), start=1)]
 
 
 def write_summary(summary, out_file):
-    writer = csv.writer(out_file, delimiter="\t")
-    writer.writerow(["cluster_id", "count", "frequency"])
-    for cid, count, freq, _ in summary:
-        writer.writerow([cid, count, f"{freq:.6f}"])
+    """TSV `cluster_id count frequency` (frequency with 6 decimals), csv-module line endings like af.py:56-60"""
+    csv.writer(out_file, delimiter="\t").writerows(
+        [("cluster_id", "count", "frequency")] + [(cid, size, f"{freq:.6f}") for cid, size, freq, _ in summary])
 
 
 def write_details(summary, threshold, path):
-    with open(path, "w", newline="") as fh:
-        writer = csv.writer(fh, delimiter="\t")
-        writer.writerow(["sample_id", "cluster_id", "threshold"])
-        for cid, _, _, members in summary:
-            for sample in members:
-                writer.writerow([sample, cid, threshold])
+    """TSV `sample_id cluster_id threshold`, one row per sample (af.py:62-68)"""
+    with open(path, "w", newline="") as handle:
+        csv.writer(handle, delimiter="\t").writerows(
+            [("sample_id", "cluster_id", "threshold")]
+            + [(sample, cid, threshold) for cid, _, _, members in summary for sample in members])

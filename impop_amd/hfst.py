@@ -6,7 +6,7 @@ import sys
 import numpy as np
 
 from .popnames import canonicalize_identifier, expand_population, read_subset_file  # noqa: F401
-from .runtime import default_context
+from .runtime import _line_writer, default_context
 from .simfile import densify, read_dense  # noqa: F401
 from .simfile import read_similarity_file_hfst as read_similarity_file  # noqa: F401  (h-fst.py:84)
 
@@ -42,10 +42,7 @@ def calculate_fst(similarities, pop_a, pop_b, sequence_length=None, round_digits
 
 def calculate_fst_dense(names, dense, pop_a, pop_b, sequence_length=None, round_digits=None, log_file=None, ctx=None):
     """calculate_fst on an already densified table (what the drop-in CLI calls after the native ingest)."""
-    def log_print(msg):
-        if log_file:
-            print(msg, file=log_file)
-
+    log_print = _line_writer(log_file)
     overlap = pop_a & pop_b
     if overlap:  # h-fst.py:181-185
         print(f"Warning: {len(overlap)} sequences appear in both populations", file=sys.stderr)

@@ -6,21 +6,11 @@ from __future__ import annotations
 
 import sys
 
-
 from .hfst import _flags
+from .popnames import read_subset_file  # noqa: F401  (hud.py:55-62 reads its lists the same way)
 from .runtime import default_context
 from .simfile import densify, read_dense  # noqa: F401
 from .simfile import read_similarity_file_hfst as read_similarity_file  # noqa: F401  (hud.py:18-53, same reader)
-
-
-def read_subset_file(filename):
-    """hud.read_subset_file (hud.py:55-62): exact identifiers, '#' comment lines skipped."""
-    try:
-        with open(filename) as f:
-            return set(line.strip() for line in f if line.strip() and not line.startswith('#'))
-    except FileNotFoundError:
-        print(f"Error: Subset file not found: {filename}", file=sys.stderr)
-        sys.exit(1)
 
 
 def calculate_fst(similarities, pop_a, pop_b, sequence_length=None, round_digits=None, log_file=None, method="direct",
@@ -30,70 +20,60 @@ def calculate_fst(similarities, pop_a, pop_b, sequence_length=None, round_digits
                                method, threshold, ctx)
 
 
+def _log_text(method, threshold, round_digits, size_a, size_b, v, cnt, sequence_length) -> str:
+    """The `<basename>_fst.log` text of hud.py:194-289 for the values v = (fst, pi_a, pi_b, pi_xy, dxy) and the
+    kernel's counters; a log file is part of what the drop-in replaces, so the wording is the reference's."""
+    fst, pi_a, pi_b, pi_xy, dxy = v
+    grouped = method == "grouped"
+    out = ["FST Calculation", "=" * 50, f"Population A: {size_a} sequences", f"Population B: {size_b} sequences",
+           f"Method: {method}"]
+    if grouped:
+        out.append(f"Grouping threshold: {threshold}")
+    if round_digits is not None:
+        out.append(f"Rounding similarities to {round_digits} decimal places")
+    out += ["", f"Within-population diversity (π) using {method} method:"]
+    for tag, pi, size, k in (("A", pi_a, size_a, 0), ("B", pi_b, size_b, 2)):
+        if grouped:
+            out.append(f"  π{tag} = {pi:.6f} ({cnt[k]} groups from {size} sequences, {cnt[k + 1]} missing pairs)")
+        else:
+            out.append(f"  π{tag} = {pi:.6f} (from {cnt[k]} pairs, {cnt[k + 1]} missing)")
+    out += [f"  πXY = {pi_xy:.6f} (average of πA and πB)", "", "Between-population diversity (Dxy):"]
+    if grouped:
+        out.append(f"  Dxy = {dxy:.6f} (from {cnt[0]} x {cnt[2]} group pairs, {cnt[5]} missing)")
+    else:
+        out.append(f"  Dxy = {dxy:.6f} (from {cnt[4]} pairs, {cnt[5]} missing)")
+    out.append("")
+    if dxy > 0:
+        out += ["FST calculation:", "  FST = (Dxy - πXY) / Dxy", f"      = ({dxy:.6f} - {pi_xy:.6f}) / {dxy:.6f}", f"      = {fst:.6f}"]
+    else:
+        out.append("FST = 0 (Dxy = 0)")
+    if sequence_length and sequence_length > 0:
+        out += ["", f"Per-site values (sequence length = {sequence_length:,}):"]
+        out += [f"  {label} per site = {value / sequence_length:.8f}"
+                for label, value in (("πA", pi_a), ("πB", pi_b), ("πXY", pi_xy), ("Dxy", dxy))]
+    return "\n".join(out) + "\n"
+
+
 def calculate_fst_dense(names, dense, pop_a, pop_b, sequence_length=None, round_digits=None, log_file=None, method="direct",
                         threshold=0.999, ctx=None):
     """calculate_fst on a densified table whose `names` (sorted) cover both populations."""
-    def log_print(msg):
-        if log_file:
-            print(msg, file=log_file)
-
-    overlap = pop_a & pop_b
-    if overlap:  # hud.py:186-190
-        print(f"Warning: {len(overlap)} sequences appear in both populations", file=sys.stderr)
-        pop_a = pop_a - overlap
-        pop_b = pop_b - overlap
+    shared = pop_a & pop_b
+    if shared:  # members of both populations leave both (hud.py:186-190)
+        print(f"Warning: {len(shared)} sequences appear in both populations", file=sys.stderr)
+        pop_a, pop_b = pop_a - shared, pop_b - shared
     ctx = ctx or default_context()
-    missing = (set(pop_a) | set(pop_b)) - set(names)
-    if missing:
-        raise KeyError(f"{len(missing)} population members absent from the identity table's name list")
+    strangers = (set(pop_a) | set(pop_b)) - set(names)
+    if strangers:
+        raise KeyError(f"{len(strangers)} population members absent from the identity table's name list")
     fa, fb = _flags(names, pop_a), _flags(names, pop_b)
     if method == "grouped":
         out, cnt = ctx.fst_grouped_from_identity(dense, fa, fb, threshold, None, round_digits)
     else:
         out, cnt = ctx.fst_from_identity(dense, fa, fb, None, round_digits)
-    fst, pi_a, pi_b, pi_xy, dxy = (float(v) for v in out[:5])
-    cnt = [int(c) for c in cnt]
-
-    log_print("FST Calculation")
-    log_print("=" * 50)
-    log_print(f"Population A: {len(pop_a)} sequences")
-    log_print(f"Population B: {len(pop_b)} sequences")
-    log_print(f"Method: {method}")
-    if method == 'grouped':
-        log_print(f"Grouping threshold: {threshold}")
-    if round_digits is not None:
-        log_print(f"Rounding similarities to {round_digits} decimal places")
-    log_print("")
-    if method == 'grouped':
-        log_print("Within-population diversity (π) using grouped method:")
-        log_print(f"  πA = {pi_a:.6f} ({cnt[0]} groups from {len(pop_a)} sequences, {cnt[1]} missing pairs)")
-        log_print(f"  πB = {pi_b:.6f} ({cnt[2]} groups from {len(pop_b)} sequences, {cnt[3]} missing pairs)")
-    else:
-        log_print("Within-population diversity (π) using direct method:")
-        log_print(f"  πA = {pi_a:.6f} (from {cnt[0]} pairs, {cnt[1]} missing)")
-        log_print(f"  πB = {pi_b:.6f} (from {cnt[2]} pairs, {cnt[3]} missing)")
-    log_print(f"  πXY = {pi_xy:.6f} (average of πA and πB)")
-    log_print("")
-    log_print("Between-population diversity (Dxy):")
-    if method == 'grouped':
-        log_print(f"  Dxy = {dxy:.6f} (from {cnt[0]} x {cnt[2]} group pairs, {cnt[5]} missing)")
-    else:
-        log_print(f"  Dxy = {dxy:.6f} (from {cnt[4]} pairs, {cnt[5]} missing)")
-    log_print("")
-    if dxy > 0:
-        log_print("FST calculation:")
-        log_print("  FST = (Dxy - πXY) / Dxy")
-        log_print(f"      = ({dxy:.6f} - {pi_xy:.6f}) / {dxy:.6f}")
-        log_print(f"      = {fst:.6f}")
-    else:
-        log_print("FST = 0 (Dxy = 0)")
-    if sequence_length and sequence_length > 0:  # hud.py:283-299
-        log_print("")
-        log_print(f"Per-site values (sequence length = {sequence_length:,}):")
-        log_print(f"  πA per site = {pi_a/sequence_length:.8f}")
-        log_print(f"  πB per site = {pi_b/sequence_length:.8f}")
-        log_print(f"  πXY per site = {pi_xy/sequence_length:.8f}")
-        log_print(f"  Dxy per site = {dxy/sequence_length:.8f}")
-        return {'fst': fst, 'pi_a': pi_a / sequence_length, 'pi_b': pi_b / sequence_length,
-                'pi_xy': pi_xy / sequence_length, 'dxy': dxy / sequence_length, 'da': (dxy - pi_xy) / sequence_length}
-    return {'fst': fst, 'pi_a': pi_a, 'pi_b': pi_b, 'pi_xy': pi_xy, 'dxy': dxy, 'da': dxy - pi_xy}
+    fst, pi_a, pi_b, pi_xy, dxy = (float(x) for x in out[:5])
+    if log_file:
+        log_file.write(_log_text(method, threshold, round_digits, len(pop_a), len(pop_b), (fst, pi_a, pi_b, pi_xy, dxy),
+                                 [int(c) for c in cnt], sequence_length))
+    scale = sequence_length if (sequence_length and sequence_length > 0) else 1  # Fst itself is never divided
+    return {"fst": fst, "pi_a": pi_a / scale, "pi_b": pi_b / scale, "pi_xy": pi_xy / scale, "dxy": dxy / scale,
+            "da": (dxy - pi_xy) / scale}

@@ -4,7 +4,7 @@ from __future__ import annotations
 
 import math
 
-from .runtime import default_context
+from .runtime import _line_writer, default_context
 from .simfile import densify
 from .simfile import read_dense  # noqa: F401
 from .simfile import read_similarity_file_pica2 as read_similarity_file  # noqa: F401  (pica2.py:6)
@@ -19,10 +19,6 @@ def analyze_similarity_matrix(similarity_dict, elements, pair_count, threshold=1
     place when round_digits is given (pica2.py:81-83).  The one documented difference:
     each greedy group is seeded with the lexicographically smallest remaining element,
     where the reference pops an arbitrary set member (pica2.py:100)."""
-    def log_print(message):
-        if log_file:
-            print(message, file=log_file)
-
     if round_digits is not None:  # caller-visible side effect of the reference
         for key in list(similarity_dict.keys()):
             similarity_dict[key] = round(similarity_dict[key], round_digits)
@@ -36,10 +32,7 @@ def analyze_dense(names, dense, pair_count, threshold=1.0, sequence_length=None,
                   ctx=None):
     """Same analysis on an already densified table (sorted names, [n,n] identity, NaN = absent):
     what the drop-in CLI calls after the native .sim ingest (simfile.read_dense)."""
-    def log_print(message):
-        if log_file:
-            print(message, file=log_file)
-
+    log_print = _line_writer(log_file)
     log_print(f"Loaded {pair_count} pairwise similarities")
     log_print(f"Found {len(names)} unique elements")
     if round_digits is not None:

@@ -1,50 +1,50 @@
-"""Population-list -> sequence-name expansion (h-fst.py:18-82, 121-128).  String
-handling only; mirrors the reference's matching rules exactly."""
+"""Population list -> sequence names (the matching rules of h-fst.py:18-82, 121-128): an assembly
+name such as `HG00097_hap1_hprc_r2_v1.0.1` selects the PanSN sequences starting with `HG00097#1#`.
+String handling only."""
 from __future__ import annotations
 
 import sys
 
-_SUFFIX_MAP = (("_hap1", "#1#"), ("_hap2", "#2#"), ("_mat", "#1#"), ("_pat", "#2#"))  # h-fst.py:44-49
+# assembly-name endings and the haplotype digit they stand for, tried in this order
+_HAPLOTYPE_OF_ENDING = (("_hap1", "1"), ("_hap2", "2"), ("_mat", "1"), ("_pat", "2"))
 
 
 def canonicalize_identifier(identifier: str) -> str:
-    """h-fst.py:18-61: assembly name -> PanSN prefix usable with str.startswith()."""
-    if not identifier:
+    """The `startswith` prefix an identifier selects; "" for blank lines and `#` comments."""
+    name = (identifier or "").strip()
+    if name == "" or name[0] == "#":
         return ""
-    token = identifier.strip()
-    if not token or token.startswith("#"):
-        return ""
-    if "_hprc" in token:  # trailing metadata, h-fst.py:41-42
-        token = token.split("_hprc", 1)[0]
-    for suffix, hap_tag in _SUFFIX_MAP:
-        if token.endswith(suffix):
-            return f"{token[:-len(suffix)]}{hap_tag}"
-    if "#" in token:  # already carries a hap delimiter, h-fst.py:57-58
-        return token if token.endswith("#") else f"{token}#"
-    return f"{token}#"  # both haplotypes of the sample, h-fst.py:61
+    name = name.partition("_hprc")[0]  # release metadata behind the assembly name
+    for ending, digit in _HAPLOTYPE_OF_ENDING:
+        if name.endswith(ending):
+            return name[: len(name) - len(ending)] + "#" + digit + "#"
+    # a name that already ends a PanSN field is kept; anything else (a bare sample: both haplotypes) gets one
+    return name if name.endswith("#") else name + "#"
 
 
 def expand_population(raw_ids, all_sequences):
-    """h-fst.py:64-82 -> (expanded set, ids that matched nothing)"""
-    expanded = set()
-    missing = []
-    for raw_id in raw_ids:
-        prefix = canonicalize_identifier(raw_id)
-        if not prefix:
+    """-> (set of sequence names selected by any identifier, identifiers that selected nothing)"""
+    pool = tuple(all_sequences)
+    selected, unmatched = set(), []
+    for rid in raw_ids:
+        key = canonicalize_identifier(rid)
+        if not key:
             continue
-        matches = {seq for seq in all_sequences if seq.startswith(prefix)}
-        if matches:
-            expanded.update(matches)
+        hits = [seq for seq in pool if seq.startswith(key)]
+        if hits:
+            selected.update(hits)
         else:
-            missing.append(raw_id)
-    return expanded, missing
+            unmatched.append(rid)
+    return selected, unmatched
 
 
 def read_subset_file(filename):
-    """h-fst.py:121-128"""
+    """Non-blank lines that do not start with `#`, stripped; a missing file ends the process like the
+    reference's reader does (message on stderr, exit code 1)."""
     try:
-        with open(filename) as f:
-            return set(line.strip() for line in f if line.strip() and not line.startswith("#"))
+        handle = open(filename)
     except FileNotFoundError:
         print(f"Error: Subset file not found: {filename}", file=sys.stderr)
         sys.exit(1)
+    with handle:
+        return {ln.strip() for ln in handle if ln.strip() and ln[0] != "#"}

@@ -22,3 +22,10 @@ def default_context() -> Context:
 def set_default_context(ctx: Optional[Context]) -> None:
     global _default
     _default = ctx
+
+
+def _line_writer(sink):
+    """print-like callable writing one line per call to `sink`, or doing nothing when there is no log file"""
+    if not sink:
+        return lambda text: None
+    return lambda text: print(text, file=sink)

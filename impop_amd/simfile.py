@@ -12,77 +12,94 @@ import numpy as np
 REQUIRED_COLS = {"group.a", "group.b", "estimated.identity"}
 
 
-def read_similarity_file_pica2(filename):
-    """pica2.read_similarity_file (pica2.py:6-58): same return value, same messages
-    (stdout) and exit codes."""
+class _Flavor:
+    """How one of the reference's two `.sim` readers reports problems.  The message texts, the stream
+    they go to and which conditions are fatal are the scripts' observable interface (the bash drivers
+    and the CLI goldens see them); the reading loop itself is shared."""
+
+    def __init__(self, stream, empty_msg, empty_when_falsy, cols_msgs, bad_value_msg, bad_value_fatal, bad_value_errors,
+                 not_found_msg, wrap_other_errors, no_rows_msg):
+        self.stream = stream                      # None = stdout
+        self.empty_msg = empty_msg
+        self.empty_when_falsy = empty_when_falsy  # h-fst treats [] like None; pica2 only None
+        self.cols_msgs = cols_msgs
+        self.bad_value_msg = bad_value_msg
+        self.bad_value_fatal = bad_value_fatal
+        self.bad_value_errors = bad_value_errors
+        self.not_found_msg = not_found_msg
+        self.wrap_other_errors = wrap_other_errors
+        self.no_rows_msg = no_rows_msg
+
+    def say(self, text):
+        print(text, file=self.stream if self.stream is not None else sys.stdout)
+
+    def die(self, *texts):
+        for t in texts:
+            self.say(t)
+        sys.exit(1)
+
+
+def _flavor(kind: str) -> _Flavor:
+    if kind == "pica2":  # pica2.py:6-58: everything on stdout, a bad number is fatal, any other exception is reported
+        return _Flavor(None, "Error: File {f} is empty or missing a header", False,
+                       lambda found: (f"Error: File must contain columns: {sorted(REQUIRED_COLS)}", f"Found columns: {found}"),
+                       "Error: Invalid similarity value on line {line}: {val}", True, (TypeError, ValueError),
+                       "Error: File not found {f}", "Error reading file {f}: {e}", "Warning: No similarity entries found in {f}")
+    # h-fst.py:84-119 (and hud.py:18-53): stderr, a bad number is skipped with a warning
+    return _Flavor(sys.stderr, "Error: Empty file {f}", True,
+                   lambda found: (f"Error: File must contain columns: {REQUIRED_COLS}", f"Found: {found}"),
+                   "Warning: Invalid similarity value: {val}", False, (ValueError,),
+                   "Error: File not found: {f}", None, None)
+
+
+def _read_table(filename, fl: _Flavor):
+    """-> (dict keyed by the name pair in string order, set of names, number of data rows read)"""
+    table: Dict[Tuple[str, str], float] = {}
+    seen: Set[str] = set()
+    n_rows = 0
     try:
         with open(filename, newline="") as handle:
-            reader = csv.DictReader(handle, delimiter="\t")
-            if reader.fieldnames is None:
-                print(f"Error: File {filename} is empty or missing a header")
-                sys.exit(1)
-            missing_cols = REQUIRED_COLS - set(reader.fieldnames)
-            if missing_cols:
-                print(f"Error: File must contain columns: {sorted(REQUIRED_COLS)}")
-                print(f"Found columns: {reader.fieldnames}")
-                sys.exit(1)
-            similarity_dict: Dict[Tuple[str, str], float] = {}
-            elements: Set[str] = set()
-            pair_count = 0
-            for row_number, row in enumerate(reader, start=2):
-                pair_count += 1
-                e1, e2 = row["group.a"], row["group.b"]
+            rows = csv.DictReader(handle, delimiter="\t")
+            header = rows.fieldnames
+            if header is None or (fl.empty_when_falsy and not header):
+                fl.die(fl.empty_msg.format(f=filename))
+            if not REQUIRED_COLS <= set(header):
+                fl.die(*fl.cols_msgs(header))
+            for line_no, rec in enumerate(rows, start=2):  # line 1 is the header
+                n_rows += 1
+                first, second, text = rec["group.a"], rec["group.b"], rec["estimated.identity"]
                 try:
-                    similarity = float(row["estimated.identity"])
-                except (TypeError, ValueError):
-                    print(f"Error: Invalid similarity value on line {row_number}: {row['estimated.identity']}")
-                    sys.exit(1)
-                key = (e1, e2) if e1 <= e2 else (e2, e1)
-                similarity_dict[key] = similarity
-                elements.add(e1)
-                elements.add(e2)
-            if pair_count == 0:
-                print(f"Warning: No similarity entries found in {filename}")
-            return similarity_dict, elements, pair_count
+                    value = float(text)
+                except fl.bad_value_errors:
+                    msg = fl.bad_value_msg.format(line=line_no, val=text)
+                    if fl.bad_value_fatal:
+                        fl.die(msg)
+                    fl.say(msg)
+                    continue
+                table[(first, second) if first <= second else (second, first)] = value  # later rows overwrite
+                seen.update((first, second))
     except FileNotFoundError:
-        print(f"Error: File not found {filename}")
-        sys.exit(1)
+        fl.die(fl.not_found_msg.format(f=filename))
     except SystemExit:
         raise
-    except Exception as e:  # pica2.py:56-58
-        print(f"Error reading file {filename}: {e}")
-        sys.exit(1)
+    except Exception as e:
+        if fl.wrap_other_errors is None:
+            raise
+        fl.die(fl.wrap_other_errors.format(f=filename, e=e))
+    if n_rows == 0 and fl.no_rows_msg:
+        fl.say(fl.no_rows_msg.format(f=filename))
+    return table, seen, n_rows
+
+
+def read_similarity_file_pica2(filename):
+    """Behaves like pica2.read_similarity_file (pica2.py:6-58) -> (dict, set of names, row count)."""
+    return _read_table(filename, _flavor("pica2"))
 
 
 def read_similarity_file_hfst(filename):
-    """h-fst.read_similarity_file (h-fst.py:84-119): bad floats are warned and skipped,
-    diagnostics go to stderr."""
-    try:
-        with open(filename, newline="") as f:
-            reader = csv.DictReader(f, delimiter="\t")
-            if not reader.fieldnames:
-                print(f"Error: Empty file {filename}", file=sys.stderr)
-                sys.exit(1)
-            if not REQUIRED_COLS.issubset(set(reader.fieldnames)):
-                print(f"Error: File must contain columns: {REQUIRED_COLS}", file=sys.stderr)
-                print(f"Found: {reader.fieldnames}", file=sys.stderr)
-                sys.exit(1)
-            similarities: Dict[Tuple[str, str], float] = {}
-            all_sequences: Set[str] = set()
-            for row in reader:
-                seq1, seq2 = row["group.a"], row["group.b"]
-                try:
-                    sim = float(row["estimated.identity"])
-                except ValueError:
-                    print(f"Warning: Invalid similarity value: {row['estimated.identity']}", file=sys.stderr)
-                    continue
-                key = (seq1, seq2) if seq1 <= seq2 else (seq2, seq1)
-                similarities[key] = sim
-                all_sequences.update([seq1, seq2])
-            return similarities, all_sequences
-    except FileNotFoundError:
-        print(f"Error: File not found: {filename}", file=sys.stderr)
-        sys.exit(1)
+    """Behaves like h-fst.read_similarity_file (h-fst.py:84-119) -> (dict, set of names)."""
+    table, seen, _ = _read_table(filename, _flavor("hfst"))
+    return table, seen
 
 
 def densify(similarity_dict, names: Sequence[str]) -> np.ndarray:

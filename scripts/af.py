@@ -1,30 +1,32 @@
 #!/usr/bin/env python3
-"""Drop-in for the reference's scripts/af.py CLI (af.py:70-92)."""
-import argparse
+"""Drop-in for the reference's scripts/af.py command line (af.py:70-92): haplotype clusters at an identity
+threshold, summary TSV on stdout (or --output) and optional per-sample assignments."""
 import sys
 
 import _bootstrap  # noqa: F401
+from _cli import make_parser
 from impop_amd.af import build_summary, cluster, load_pairs, write_details, write_summary
+
+FLAGS = (
+    ("--input", dict(default="loc.sim", help="identity table to cluster (loc.sim)")),
+    ("--threshold", dict(type=float, default=1.0, help="samples at least this identical are linked (1.0)")),
+    ("--output", dict(help="write the cluster summary here instead of stdout")),
+    ("--details", dict(help="also write sample_id / cluster_id / threshold rows here")),
+)
 
 
 def main():
-    parser = argparse.ArgumentParser(description='Cluster samples in loc.sim-style tables by identity threshold.')
-    parser.add_argument('--input', default='loc.sim', help='Path to the similarity table (default: loc.sim)')
-    parser.add_argument('--threshold', type=float, default=1.0, help='Minimum estimated.identity to link samples (default: 1.0)')
-    parser.add_argument('--output', help='Optional output TSV path for cluster summary; stdout if omitted')
-    parser.add_argument('--details', help='Optional path to write detailed sample assignments')
-    args = parser.parse_args()
-    rows, samples = load_pairs(args.input)
-    clusters = cluster(rows, samples, args.threshold)
-    summary = build_summary(clusters)
-    if args.output:
-        with open(args.output, 'w', newline='') as fh:
-            write_summary(summary, fh)
+    opt = make_parser("Cluster the samples of an identity table and report cluster frequencies.", FLAGS).parse_args()
+    pairs, samples = load_pairs(opt.input)
+    summary = build_summary(cluster(pairs, samples, opt.threshold))
+    if opt.output:
+        with open(opt.output, "w", newline="") as sink:
+            write_summary(summary, sink)
     else:
         write_summary(summary, sys.stdout)
-    if args.details:
-        write_details(summary, args.threshold, args.details)
+    if opt.details:
+        write_details(summary, opt.threshold, opt.details)
 
 
-if __name__ == '__main__':
+if __name__ == "__main__":
     main()

@@ -1,26 +1,27 @@
 #!/usr/bin/env python3
-"""Drop-in for the reference's scripts/wip/ehhgfa.py CLI (ehhgfa.py:24-71): same flags, same rows
-`window colstart colend allele REF|ALT area` written to -o."""
-import argparse
-
+"""Drop-in for the reference's scripts/wip/ehhgfa.py command line (ehhgfa.py:24-71): same flags; one
+row `window colstart colend allele REF|ALT area` per window and test-SNP allele, written to -o."""
 import numpy as np
 
 import _bootstrap  # noqa: F401
+from _cli import make_parser
 from impop_amd.ehh import scan_windows
+
+FLAGS = (
+    ("-i", dict(help="haplotype matrix as whitespace-separated numbers, one haplotype per row, no header")),
+    ("-p", dict(type=int, help="1-based column of the test SNP inside each window")),
+    ("-w", dict(type=int, help="window width in columns")),
+    ("-refpos", dict(type=int, help="1-based row of the haplotype whose allele is called REF")),
+    ("-o", dict(type=str, help="output file")),
+)
 
 
 def main():
-    parser = argparse.ArgumentParser()
-    parser.add_argument("-i", help="Path to the input file, matrix of haplotypes, no header")
-    parser.add_argument("-p", type=int, help="Position of the test SNP in the haplotype window")
-    parser.add_argument("-w", type=int, help="Window size")
-    parser.add_argument("-refpos", type=int, help="reference position ")
-    parser.add_argument("-o", type=str, help="outputfile  ")
-    args = parser.parse_args()
-    with open(args.o, "w") as out:
-        whole = np.loadtxt(args.i)
-        for name, colstart, colend, al, typeal, area in scan_windows(whole, args.p, args.w, args.refpos):
-            print(name, colstart, colend, al, typeal, area, file=out, flush=True)
+    opt = make_parser("Integrated EHH around a test SNP, window by window.", FLAGS).parse_args()
+    with open(opt.o, "w") as sink:
+        matrix = np.loadtxt(opt.i)
+        for row in scan_windows(matrix, opt.p, opt.w, opt.refpos):
+            print(*row, file=sink, flush=True)
 
 
 if __name__ == "__main__":

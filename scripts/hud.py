@@ -1,64 +1,60 @@
 #!/usr/bin/env python3
-"""Drop-in for the reference's scripts/hudson/hud.py CLI (hud.py:310-415): same flags (incl.
--m direct|grouped, -t), stderr diagnostics, `<base>_fst.log` and the 6 tab-separated `.8f` fields."""
-import argparse
-import os
+"""Drop-in for the reference's scripts/hudson/hud.py command line (hud.py:310-415): h-fst's flags plus
+`-m direct|grouped` and `-t`; population files hold exact sequence names; same stderr notes, `<basename>_fst.log`
+and six `.8f` fields on stdout."""
 import sys
 
 import _bootstrap  # noqa: F401
+from _cli import log_path_for, make_parser
 from impop_amd.hud import calculate_fst_dense, read_dense, read_subset_file
+
+FLAGS = (
+    ("similarity_file", dict(help=".sim table: TSV with group.a, group.b, estimated.identity")),
+    ("-a", "--pop-a", dict(required=True, help="sequence names of population A, one per line")),
+    ("-b", "--pop-b", dict(required=True, help="sequence names of population B")),
+    ("-l", "--length", dict(type=int, default=None, help="window length: the diversities are divided by it")),
+    ("-r", "--round", dict(type=int, default=None, help="round identities to this many decimals")),
+    ("-m", "--method", dict(choices=["direct", "grouped"], default="direct",
+                            help="direct: mean over sequence pairs; grouped: frequency-weighted over groups of similar sequences")),
+    ("-t", "--threshold", dict(type=float, default=0.999, help="grouping threshold of -m grouped (0.999)")),
+    ("-d", "--log-dir", dict(default=".", help="where <basename>_fst.log goes (current directory)")),
+    ("-v", "--verbose", dict(action="store_true", help="progress notes on stderr")),
+)
+FIELDS = ("fst", "pi_a", "pi_b", "pi_xy", "dxy", "da")
+
+
+def note(text):
+    print(text, file=sys.stderr)
 
 
 def main():
-    parser = argparse.ArgumentParser(description='Calculate FST from pairwise sequence similarities')
-    parser.add_argument('similarity_file', help='TSV file with columns: group.a, group.b, estimated.identity')
-    parser.add_argument('-a', '--pop-a', required=True, help='File listing sequence IDs for population A')
-    parser.add_argument('-b', '--pop-b', required=True, help='File listing sequence IDs for population B')
-    parser.add_argument('-l', '--length', type=int, default=None, help='Sequence length for per-site calculations')
-    parser.add_argument('-r', '--round', type=int, default=None, help='Round similarities to N decimal places')
-    parser.add_argument('-m', '--method', choices=['direct', 'grouped'], default='direct',
-                        help='Calculation method: direct or grouped (default: direct)')
-    parser.add_argument('-t', '--threshold', type=float, default=0.999,
-                        help='Similarity threshold for grouping (default: 0.999, used only with -m grouped)')
-    parser.add_argument('-d', '--log-dir', default='.', help='Directory for log file (default: current directory)')
-    parser.add_argument('-v', '--verbose', action='store_true', help='Print detailed progress to stderr')
-    args = parser.parse_args()
-
-    if args.verbose:
-        print(f"Reading similarity file: {args.similarity_file}", file=sys.stderr)
-    names, dense, _ = read_dense(args.similarity_file, "hfst")
-    all_sequences = set(names)
-    if args.verbose:
-        print("Reading population files...", file=sys.stderr)
-    pop_a = read_subset_file(args.pop_a)
-    pop_b = read_subset_file(args.pop_b)
-    if args.verbose:
-        print(f"Population A: {len(pop_a)} sequences", file=sys.stderr)
-        print(f"Population B: {len(pop_b)} sequences", file=sys.stderr)
-        print(f"Method: {args.method}", file=sys.stderr)
-        if args.method == 'grouped':
-            print(f"Grouping threshold: {args.threshold}", file=sys.stderr)
-    missing_a = pop_a - all_sequences
-    missing_b = pop_b - all_sequences
-    if missing_a:
-        print(f"Warning: {len(missing_a)} sequences from population A not found in similarity file", file=sys.stderr)
-    if missing_b:
-        print(f"Warning: {len(missing_b)} sequences from population B not found in similarity file", file=sys.stderr)
-    pop_a = pop_a & all_sequences
-    pop_b = pop_b & all_sequences
-    if not pop_a or not pop_b:
-        print("Error: No valid sequences found in one or both populations", file=sys.stderr)
+    opt = make_parser("Hudson Fst (direct or grouped) of two populations from a pairwise identity table.", FLAGS).parse_args()
+    chatty = note if opt.verbose else (lambda text: None)
+    chatty(f"Reading similarity file: {opt.similarity_file}")
+    names, dense, _ = read_dense(opt.similarity_file, "hfst")
+    known = set(names)
+    chatty("Reading population files...")
+    pops = {tag: read_subset_file(path) for tag, path in (("A", opt.pop_a), ("B", opt.pop_b))}
+    for tag in ("A", "B"):
+        chatty(f"Population {tag}: {len(pops[tag])} sequences")
+    chatty(f"Method: {opt.method}")
+    if opt.method == "grouped":
+        chatty(f"Grouping threshold: {opt.threshold}")
+    for tag in ("A", "B"):
+        absent = pops[tag] - known
+        if absent:
+            note(f"Warning: {len(absent)} sequences from population {tag} not found in similarity file")
+    for tag in ("A", "B"):
+        pops[tag] &= known
+    if not pops["A"] or not pops["B"]:
+        note("Error: No valid sequences found in one or both populations")
         sys.exit(1)
-    base_name = os.path.splitext(os.path.basename(args.similarity_file))[0]
-    log_path = os.path.join(args.log_dir, f"{base_name}_fst.log")
-    os.makedirs(args.log_dir, exist_ok=True)
-    with open(log_path, 'w') as log_file:
-        results = calculate_fst_dense(names, dense, pop_a, pop_b, sequence_length=args.length, round_digits=args.round,
-                                      log_file=log_file, method=args.method, threshold=args.threshold)
-    print(f"{results['fst']:.8f}\t{results['pi_a']:.8f}\t{results['pi_b']:.8f}\t"
-          f"{results['pi_xy']:.8f}\t{results['dxy']:.8f}\t{results['da']:.8f}")
-    if args.verbose:
-        print(f"Detailed log saved to: {log_path}", file=sys.stderr)
+    log_name = log_path_for(opt.similarity_file, opt.log_dir, "_fst")
+    with open(log_name, "w") as log:
+        res = calculate_fst_dense(names, dense, pops["A"], pops["B"], sequence_length=opt.length, round_digits=opt.round,
+                                  log_file=log, method=opt.method, threshold=opt.threshold)
+    print("\t".join(f"{res[k]:.8f}" for k in FIELDS))
+    chatty(f"Detailed log saved to: {log_name}")
 
 
 if __name__ == "__main__":

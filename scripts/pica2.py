@@ -1,46 +1,42 @@
 #!/usr/bin/env python3
-"""Drop-in for the reference's scripts/pica2.py CLI (pica2.py:172-228): same flags, same log
-file, same stdout — `"{pi_per_site:.8f} (sequence length: L)"` — with the analysis on the GPU."""
-import argparse
-import os
-
+"""Drop-in for the reference's scripts/pica2.py command line (pica2.py:172-228): same flags, same
+`<log-dir>/<basename>.log`, same single stdout line `<value> (sequence length: L)` whose first token the
+bash drivers read — the analysis itself runs on the GPU."""
 import _bootstrap  # noqa: F401
+from _cli import log_path_for, make_parser
 from impop_amd.pica2 import analyze_dense, read_dense
 
-if __name__ == "__main__":
-    parser = argparse.ArgumentParser(description='Analyze similarity matrix with customizable threshold and sequence length normalization')
-    parser.add_argument('input_file', help='Input file with similarity data (TSV format with group.a, group.b, estimated.identity columns)')
-    parser.add_argument('--threshold', '-t', type=float, default=0.99,
-                        help='Similarity threshold for grouping elements (default: 0.99)')
-    parser.add_argument('--sequence-length', '-l', type=int, help='Sequence length for normalizing pi per site')
-    parser.add_argument('--log-dir', '-d', type=str, default='.', help='Directory to save log file (default: current directory)')
-    parser.add_argument('--round-digits', '-r', type=int, default=None,
-                        help='Round similarity values to specified decimal places (default: no rounding)')
-    args = parser.parse_args()
+FLAGS = (
+    ("input_file", dict(help=".sim table: TSV with at least group.a, group.b, estimated.identity")),
+    ("--threshold", "-t", dict(type=float, default=0.99, help="sequences more similar than this to a group's seed join it (0.99)")),
+    ("--sequence-length", "-l", dict(type=int, help="divide pi by this length and print the per-site value")),
+    ("--log-dir", "-d", dict(type=str, default=".", help="where <basename>.log goes (current directory)")),
+    ("--round-digits", "-r", dict(type=int, default=None, help="round every identity to this many decimals first")),
+)
 
-    base_name = os.path.splitext(os.path.basename(args.input_file))[0]
-    log_filename = os.path.join(args.log_dir, f"{base_name}.log")
-    os.makedirs(args.log_dir, exist_ok=True)
-    names, dense, pair_count = read_dense(args.input_file, "pica2")  # native ingest; reference messages on errors
-    with open(log_filename, 'w') as log_file:
-        log_file.write("Nucleotide Diversity Analysis Log\n")
-        log_file.write("=================================\n")
-        log_file.write(f"Input file: {args.input_file}\n")
-        log_file.write(f"Threshold: {args.threshold}\n")
-        if args.sequence_length:
-            log_file.write(f"Sequence length: {args.sequence_length}\n")
-        if args.round_digits is not None:
-            log_file.write(f"Similarity rounding: {args.round_digits} decimal places\n")
-        log_file.write(f"Log file: {log_filename}\n\n")
-        pi, pi_per_site = analyze_dense(names, dense, pair_count, threshold=args.threshold,
-                                        sequence_length=args.sequence_length, log_file=log_file,
-                                        round_digits=args.round_digits)
-        log_file.write("\n" + "=" * 50 + "\n")
-        log_file.write("FINAL RESULTS:\n")
-        log_file.write(f"pi = {pi:.6f}\n")
-        if pi_per_site is not None:
-            log_file.write(f"pi per site = {pi_per_site:.8f}\n")
-    if args.sequence_length:
-        print(f"{pi_per_site:.8f} (sequence length: {args.sequence_length})")
-    else:
-        print(f"{pi:.6f} (sequence length: {args.sequence_length})")
+
+def main():
+    opt = make_parser("Nucleotide diversity of one window from its pairwise identity table.", FLAGS).parse_args()
+    log_name = log_path_for(opt.input_file, opt.log_dir)
+    names, dense, n_rows = read_dense(opt.input_file, "pica2")  # native ingest; the reference's messages on errors
+    head = ["Nucleotide Diversity Analysis Log", "=================================", f"Input file: {opt.input_file}",
+            f"Threshold: {opt.threshold}"]
+    if opt.sequence_length:
+        head.append(f"Sequence length: {opt.sequence_length}")
+    if opt.round_digits is not None:
+        head.append(f"Similarity rounding: {opt.round_digits} decimal places")
+    head.append(f"Log file: {log_name}\n")
+    with open(log_name, "w") as log:
+        log.write("\n".join(head) + "\n")
+        pi, per_site = analyze_dense(names, dense, n_rows, threshold=opt.threshold, sequence_length=opt.sequence_length,
+                                     log_file=log, round_digits=opt.round_digits)
+        tail = ["", "=" * 50, "FINAL RESULTS:", f"pi = {pi:.6f}"]
+        if per_site is not None:
+            tail.append(f"pi per site = {per_site:.8f}")
+        log.write("\n".join(tail) + "\n")
+    value = f"{per_site:.8f}" if opt.sequence_length else f"{pi:.6f}"
+    print(f"{value} (sequence length: {opt.sequence_length})")
+
+
+if __name__ == "__main__":
+    main()

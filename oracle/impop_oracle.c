@@ -2,7 +2,8 @@
  * impop_oracle.c — CPU ORACLE (test infrastructure, NOT product code).
  *
  * A plain-C restatement of the pairwise-diversity hot path of pangenome/impop
- * (scripts/pica2.py, scripts/h-fst.py, scripts/tj_d.py, scripts/af.py).  Every
+ * (scripts/pica2.py, scripts/h-fst.py, scripts/tj_d.py, scripts/af.py, and the
+ * extras scripts/hudson/hud.py grouped Fst and scripts/wip/ehhgfa.py EHH).  Every
  * function cites the reference file:line it follows.  It exists only so that
  * tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg can check /
  * time the HIP engine against an independent implementation.  Nothing under
@@ -12,7 +13,8 @@
  * the build container; oracle/gen_golden.py runs the real reference functions
  * on seeded inputs and stores their full-precision outputs in tests/golden/;
  * tests/test_oracle_golden.py checks this file against those vectors and the
- * known answers listed in SURVEY.md §4.  Not pinned (third-party tools absent
+ * known answers listed in SURVEY.md §4 (pica2, h-fst, tj_d, af, hud grouped and
+ * calc_EHH all have captured vectors).  Not pinned (third-party tools absent
  * from the reference tree: impg/odgi/povu): bit-matrix -> identity and the
  * segregating-site count S, which this engine *defines* (see oracle_* "engine
  * definition" comments) — parity with the reference is claimed from the

@@ -612,8 +612,21 @@ def test_compacted_matrix_gives_identical_records(ctx, oracle):
     for call in (lambda: cm.afs(wins[:2]), lambda: cm.site_counts(0, 10), lambda: cm.ehh(0, 10), lambda: cm.compact()):
         with pytest.raises(ImpopError):
             call()
+    with pytest.raises(ImpopError):
+        cm.scan([(0, W + 1, 0)])  # windows are checked against the ORIGINAL length
     cm.free()
     bm.free()
+    # no variable site at all (all haplotypes identical) and a single-haplotype matrix
+    for mat in (np.repeat(anc[None, :300], 7, axis=0), anc[None, :300]):
+        full_m = ctx.upload_dense(mat, keep_hap_major=False)
+        empty = full_m.compact()
+        assert empty.n_site == 0
+        w2 = [(0, 300, 300), (10, 20, 0), (5, 5, 0)]
+        fa = np.zeros(mat.shape[0], np.uint8); fa[:1] = 1
+        fb = np.zeros(mat.shape[0], np.uint8); fb[1:3] = 1
+        assert full_m.scan(w2, None, fa, fb).tobytes() == empty.scan(w2, None, fa, fb).tobytes()
+        empty.free()
+        full_m.free()
 
 
 def test_int8_gram_kernel_still_exact():

@@ -138,13 +138,20 @@ def main():
         if not mask_a.any() or not mask_b.any():
             print("Error: No valid sequences found in one or both populations", file=sys.stderr)  # h-fst.py:319-321
             sys.exit(1)
-    if args.panel and world > 1:
-        print("Error: --panel is not sharded yet; run it on one GPU", file=sys.stderr)
-        sys.exit(2)
     if args.panel:
         labels = [os.path.splitext(os.path.basename(f))[0] for f in args.panel]
         pops = [flags_for(f, names)[0] for f in args.panel]
         pr = bm.scan_multi(wins, pops)
+        if world > 1:  # one all-gather of [window, pair] records, a window's pairs travelling as one item
+            from impop_amd.distributed import gather_records
+            import torch
+            n_pairs = pr.shape[1]
+            item = np.dtype((np.void, n_pairs * pr.dtype.itemsize))
+            flat = np.ascontiguousarray(pr).reshape(-1).view(item) if len(pr) else np.zeros(0, dtype=item)
+            dev = torch.device("cuda", local_rank) if args.backend == "nccl" else None
+            full = gather_records(flat, len(all_wins), world, rank, dev)
+            pr = full.view(pr.dtype).reshape(len(all_wins), n_pairs)
+            wins = [(int(w["site_begin"]), int(w["site_end"]), int(w["seq_len"])) for w in all_wins]
         p = 0
         for k in range(len(pops)):
             for l in range(k + 1, len(pops)):
@@ -154,10 +161,14 @@ def main():
                     print(f"{reg}\t{L}\t{float(r['fst']):.8f}\t{float(r['pi_a']):.8f}\t{float(r['pi_b']):.8f}\t"
                           f"{float(r['pi_xy']):.8f}\t{float(r['dxy']):.8f}\t{float(r['da']):.8f}", file=out)
                 p += 1
-        if args.output:
+        if args.output or rank != 0:
             out.close()
         bm.free()
         ctx.close()
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+            dist.destroy_process_group()
         return
     if need_pairwise:
         # CLI defaults of the reference: pica2.py:175 (-t 0.99), hud.py -t 0.999

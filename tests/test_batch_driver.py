@@ -146,3 +146,16 @@ def test_batch_driver_two_ranks_equal_one(tmp_path):
                          capture_output=True, text=True)
     assert two.returncode == 0, two.stderr[-2000:]
     assert open(tmp_path / "two.tsv").read() == one.stdout
+    # the K-population panel (all pairs per window) sharded the same way
+    (tmp_path / "C.txt").write_text("\n".join(f"S{i:03d}" for i in range(15, 20)) + "\n")
+    panel = [os.path.join(ROOT, "scripts", "impop_scan.py"), "--matrix", str(tmp_path / "m.npz"), "--bed", str(tmp_path / "w.bed"),
+             "--format", "hfst", "--panel", str(tmp_path / "A.txt"), str(tmp_path / "B.txt"), str(tmp_path / "C.txt")]
+    one_p = subprocess.run([sys.executable] + panel, capture_output=True, text=True)
+    assert one_p.returncode == 0, one_p.stderr
+    assert one_p.stdout.count("# ") == 3
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    two_p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                            "127.0.0.1", "--master-port", str(port)] + panel + ["--backend", "gloo", "-o", str(tmp_path / "two_p.tsv")],
+                           capture_output=True, text=True)
+    assert two_p.returncode == 0, two_p.stderr[-2000:]
+    assert open(tmp_path / "two_p.tsv").read() == one_p.stdout

@@ -93,6 +93,7 @@ SIGNATURES = {
     "impop_matrix_free": (C.c_int, [_vp, _vp]),
     "impop_scan_plan_create": (C.c_int, [_vp, _vp, C.POINTER(Window), C.c_uint64, _u64p, _u64p, _u64p,
                                          C.POINTER(ScanParams), C.POINTER(_vp)]),
+    "impop_scan_plan_set_masks": (C.c_int, [_vp, _u64p, _u64p, _u64p]),
     "impop_scan_plan_launch": (C.c_int, [_vp, _vp]),
     "impop_scan_plan_fetch": (C.c_int, [_vp, C.POINTER(WindowStats)]),
     "impop_scan_plan_info": (C.c_int, [_vp, _u64p, _u64p]),

@@ -565,6 +565,26 @@ struct impop_scan_plan {
     size_t events_used = 0;
 };
 
+// subset masks of a plan; the overlap of A and B is removed from both (h-fst.py:181-185)
+static void plan_set_masks(impop_scan_plan *p, const uint64_t *mask_p, const uint64_t *mask_a, const uint64_t *mask_b) {
+    const uint32_t n = p->m->g.n_hap, wps = p->m->g.wps;
+    std::vector<uint32_t> mp, ma, mb;
+    mask_to_dwords(mask_p, n, wps, true, mp);
+    mask_to_dwords(mask_a, n, wps, false, ma);
+    mask_to_dwords(mask_b, n, wps, false, mb);
+    for (uint32_t k = 0; k < wps; ++k) {
+        const uint32_t ov = ma[k] & mb[k];
+        ma[k] &= ~ov; mb[k] &= ~ov;
+    }
+    p->ps.n = n; p->ps.nP = popcount_vec(mp); p->ps.nA = popcount_vec(ma); p->ps.nB = popcount_vec(mb);
+    p->subset_p = p->ps.nP != n;
+    p->masks.clear();
+    p->masks.reserve(3 * wps);
+    p->masks.insert(p->masks.end(), mp.begin(), mp.end());
+    p->masks.insert(p->masks.end(), ma.begin(), ma.end());
+    p->masks.insert(p->masks.end(), mb.begin(), mb.end());
+}
+
 template <int WPS>
 static void launch_scan_fixed(impop_scan_plan *p, hipStream_t st) {
     MaskArgs<WPS> mk;
@@ -616,21 +636,7 @@ IMPOP_API int impop_scan_plan_create(impop_ctx *ctx, const impop_matrix *m, cons
     m->users++;
     p->d_pi_mode = prm.d_pi_mode; p->s_scope = prm.s_scope;
     const uint32_t n = m->g.n_hap, wps = m->g.wps;
-    // masks; overlap of A and B is removed from both (h-fst.py:181-185)
-    std::vector<uint32_t> mp, ma, mb;
-    mask_to_dwords(mask_p, n, wps, true, mp);
-    mask_to_dwords(mask_a, n, wps, false, ma);
-    mask_to_dwords(mask_b, n, wps, false, mb);
-    for (uint32_t k = 0; k < wps; ++k) {
-        const uint32_t ov = ma[k] & mb[k];
-        ma[k] &= ~ov; mb[k] &= ~ov;
-    }
-    p->ps.n = n; p->ps.nP = popcount_vec(mp); p->ps.nA = popcount_vec(ma); p->ps.nB = popcount_vec(mb);
-    p->subset_p = p->ps.nP != n;
-    p->masks.reserve(3 * wps);
-    p->masks.insert(p->masks.end(), mp.begin(), mp.end());
-    p->masks.insert(p->masks.end(), ma.begin(), ma.end());
-    p->masks.insert(p->masks.end(), mb.begin(), mb.end());
+    plan_set_masks(p, mask_p, mask_a, mask_b);
 
     std::vector<ScanTile> tiles;
     std::vector<WinDesc> wd;
@@ -665,6 +671,17 @@ IMPOP_API int impop_scan_plan_create(impop_ctx *ctx, const impop_matrix *m, cons
     int rc = ensure_tajima_consts(ctx, p->ps.nP >= 2 ? (int64_t)p->ps.nP : 2);
     if (rc) return fail(rc);
     *out = p;
+    return IMPOP_OK;
+}
+
+IMPOP_API int impop_scan_plan_set_masks(impop_scan_plan *p, const uint64_t *mask_p, const uint64_t *mask_a,
+                                        const uint64_t *mask_b) {
+    REQUIRE(p, "impop_scan_plan_set_masks: plan is NULL");
+    HIP_TRY(hipSetDevice(p->ctx->device));
+    // launches already queued read the previous masks: kernel arguments were captured at their launch and
+    // the device copy is only rewritten behind them in stream order
+    plan_set_masks(p, mask_p, mask_a, mask_b);
+    HIP_TRY(hipMemcpyAsync(p->d_masks, p->masks.data(), p->masks.size() * 4, hipMemcpyHostToDevice, p->ctx->stream));
     return IMPOP_OK;
 }
 

@@ -395,6 +395,14 @@ class ScanPlan:
         self.n_tiles, self.bytes_streamed = t.value, b.value
         self.n_windows = len(windows)
 
+    def set_masks(self, mask_p=None, mask_a=None, mask_b=None) -> None:
+        """Swap the subset / population masks; the tile tables (windows) are kept."""
+        n = self.matrix.n_hap
+        kp, pp = _mask_ptr(mask_p, n)
+        ka, pa = _mask_ptr(mask_a, n)
+        kb, pb = _mask_ptr(mask_b, n)
+        check(self.matrix.ctx._lib.impop_scan_plan_set_masks(self._h, pp, pa, pb))
+
     def launch(self, d_out: Optional[int] = None) -> None:
         check(self.matrix.ctx._lib.impop_scan_plan_launch(self._h, C.c_void_p(d_out) if d_out else None))
 

@@ -159,6 +159,10 @@ typedef struct impop_scan_params {
 int impop_scan_plan_create(impop_ctx *ctx, const impop_matrix *m, const impop_window *windows, uint64_t n_windows,
                            const uint64_t *mask_p, const uint64_t *mask_a, const uint64_t *mask_b,
                            const impop_scan_params *params, impop_scan_plan **out);
+/* Replace the three subset masks of an existing plan (the tile tables depend on the windows only), e.g.
+ * to scan the same windows for many population pairs; takes effect for launches issued afterwards. */
+int impop_scan_plan_set_masks(impop_scan_plan *plan, const uint64_t *mask_p, const uint64_t *mask_a,
+                              const uint64_t *mask_b);
 /* Enqueue one pass over all windows on the context's stream (no host sync, no
  * allocation: graph-capturable).  d_out: device buffer of n_windows records, or
  * NULL to use the plan's internal buffer. */

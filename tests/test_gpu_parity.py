@@ -703,3 +703,24 @@ def test_pairwise_scan_grouped_fst(ctx, oracle):
                     assert a == b or (a != a and b != b), k
                 assert int(r["n_groups"]) == int(d["n_groups"])
     bm.free()
+
+
+def test_plan_mask_swap_equals_fresh_plans(ctx):
+    """impop_scan_plan_set_masks: one plan (one set of tile tables) re-used for many population pairs
+    returns, pair after pair, exactly what a fresh plan returns — fixed-WPS and any-n kernels."""
+    rng = np.random.default_rng(8)
+    for n, W in ((77, 9000), (600, 4000)):
+        m01 = (rng.random((n, W)) < rng.random(W) * 0.5).astype(np.uint8)
+        bm = ctx.upload_dense(m01, keep_hap_major=False)
+        wins = [(0, W, W), (100, 2100, 2000), (2000, 4000, 50000), (3999, 4000, 1)]
+        plan = bm.plan(wins, None, None, None)
+        pops = [(rng.random(n) < 0.3).astype(np.uint8) for _ in range(4)]
+        sub = (rng.random(n) < 0.7).astype(np.uint8)
+        for mp in (None, sub):
+            for i in range(len(pops)):
+                for j in range(i + 1, len(pops)):
+                    plan.set_masks(mp, pops[i], pops[j])
+                    plan.launch()
+                    assert plan.fetch().tobytes() == bm.scan(wins, mp, pops[i], pops[j]).tobytes(), (n, i, j)
+        plan.destroy()
+        bm.free()

@@ -724,3 +724,37 @@ def test_plan_mask_swap_equals_fresh_plans(ctx):
                     assert plan.fetch().tobytes() == bm.scan(wins, mp, pops[i], pops[j]).tobytes(), (n, i, j)
         plan.destroy()
         bm.free()
+
+
+def test_plan_launch_is_graph_capturable():
+    """impop_scan_plan_launch does no host synchronisation and no allocation, so a hipGraph can capture
+    it on the stream handed to the context (torch is only the capture harness here) and replay it."""
+    import torch
+
+    import impop_amd
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        ctx = impop_amd.Context(0, stream=s.cuda_stream)
+        n, W, NW = 465, 5000, 64
+        bm = ctx.synthetic(n, W * NW, seed=3)
+        in_a = np.zeros(n, np.uint8); in_a[:140] = 1
+        in_b = np.zeros(n, np.uint8); in_b[140:240] = 1
+        plan = bm.plan(impop_amd.fixed_windows(W * NW, W), None, in_a, in_b)
+        out = torch.zeros(NW * 128, dtype=torch.uint8, device="cuda")
+        plan.launch(out.data_ptr())
+        s.synchronize()
+        want = out.clone()
+        out.zero_()
+        s.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=s):
+            plan.launch(out.data_ptr())
+        assert int(out.sum()) == 0  # capture records, it does not run
+        for _ in range(3):
+            g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out, want)
+        del g
+        plan.destroy()
+        bm.free()
+        ctx.close()

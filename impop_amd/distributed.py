@@ -71,3 +71,25 @@ def scan_sharded(windows: np.ndarray, local_scan: Callable[[np.ndarray, int, int
     loc, s0, s1, _ = shard_windows(windows, world, rank)
     rec = local_scan(loc, s0, s1)
     return gather_records(rec, len(windows), world, rank, device)
+
+
+def pairwise_counts_sharded(site_begin: int, site_end: int, local_counts: Callable[[int, int], np.ndarray], world: int, rank: int,
+                            device=None) -> np.ndarray:
+    """The one place where the all-pairs path has a real exchange step (BASELINE config 5:
+    one giant window): the site axis of [site_begin, site_end) is cut into `world` contiguous ranges, every
+    rank computes the integer Gram matrix I_ij of ITS range (`local_counts(lo, hi)`, product:
+    BitMatrix.pairwise_counts on the slab resident on this GPU) and ONE all-reduce(sum) adds them up —
+    RCCL over xGMI with the "nccl" backend, gloo on the CPU for tests.  Integer sums, so the result is
+    bit-identical for any number of ranks.  Every rank returns the full n x n int64 matrix."""
+    lo, hi = shard_range(site_end - site_begin, world, rank)
+    part = np.ascontiguousarray(local_counts(site_begin + lo, site_begin + hi), dtype=np.int64)
+    if world == 1:
+        return part
+    import torch
+    import torch.distributed as dist
+
+    t = torch.from_numpy(part)
+    if device is not None:
+        t = t.to(device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return t.cpu().numpy()

@@ -83,3 +83,46 @@ def test_two_rank_gather_equals_single_process(size, step):
     w = impop_amd.fixed_windows(W, size, step)
     loc, s0, s1, (lo, hi) = shard_windows(w, 2, 1)
     assert int(loc["site_begin"].min()) == 0 and s0 == int(w[lo]["site_begin"]) and s1 == W
+
+
+def _gram_worker(rank, world, port, n, W, seed, q):
+    import sys
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from impop_amd.distributed import pairwise_counts_sharded
+    from oracle import oracle as orc
+    from synth_ref import synth_matrix
+
+    def local_counts(lo, hi):  # this rank only materialises its own site range
+        bits = orc.pack_hap_major(synth_matrix(n, lo, hi, seed=seed))
+        return orc.pairwise_counts(bits, n, 0, hi - lo)
+
+    I = pairwise_counts_sharded(13, W - 7, local_counts, world, rank)
+    q.put((rank, I.tobytes()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gram_allreduce_equals_single_process():
+    """K-split of one long window over ranks + one all-reduce(sum) of the integer Gram matrix."""
+    import torch.multiprocessing as mp
+    from oracle import oracle as orc
+    from synth_ref import synth_matrix
+    n, W, seed = 23, 5001, 4
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_gram_worker, args=(r, 2, port, n, W, seed, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert got[0] == got[1]
+    want = orc.pairwise_counts(orc.pack_hap_major(synth_matrix(n, 0, W, seed=seed)), n, 13, W - 7)
+    assert (np.frombuffer(got[0], dtype=np.int64).reshape(n, n) == want).all()

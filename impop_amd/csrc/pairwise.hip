@@ -6,6 +6,7 @@
 // (FP4 bit planes, further down); gram_mfma_kernel (int8 + look-up table) is its predecessor,
 // selectable with IMPOP_GRAM_MFMA=i8 for A/B measurements.
 #include <stdlib.h>
+#include <string.h>
 
 #include <algorithm>
 #include <type_traits>
@@ -704,7 +705,7 @@ IMPOP_API int impop_pairwise_scan(impop_ctx *ctx, const impop_matrix *m, const i
     REQUIRE(params->identity_kind == IMPOP_IDENTITY_MATCH || params->identity_kind == IMPOP_IDENTITY_DICE,
             "impop_pairwise_scan: unknown identity kind");
     REQUIRE(params->round_digits <= 19, "impop_pairwise_scan: round_digits > 19 unsupported");
-    REQUIRE(params->d_pi_mode >= 0 && params->d_pi_mode <= 2 && (params->s_scope == 0 || params->s_scope == 1),
+    REQUIRE(params->d_pi_mode >= 0 && params->d_pi_mode <= 2 && params->s_scope >= 0 && params->s_scope <= 2,
             "impop_pairwise_scan: bad d_pi_mode / s_scope");
     REQUIRE(params->fst_method <= 1, "impop_pairwise_scan: fst_method must be 0 (direct) or 1 (grouped)");
     if (!n_windows) return IMPOP_OK;
@@ -718,11 +719,14 @@ IMPOP_API int impop_pairwise_scan(impop_ctx *ctx, const impop_matrix *m, const i
     // integer S / W of the same windows from the streaming scan
     impop_scan_params sp;
     sp.struct_size = sizeof sp; sp.d_pi_mode = params->d_pi_mode; sp.s_scope = params->s_scope; sp.tile_blocks = 0;
+    // s_scope 2: the caller does not need S / Tajima's D (pica2- or Fst-only output): skip the site scan
+    const bool want_s = params->s_scope != 2;
+    if (!want_s) sp.s_scope = 0;
     impop_scan_plan *plan = nullptr;
-    int rc = impop_scan_plan_create(ctx, m, windows, n_windows, mask_p, mask_a, mask_b, &sp, &plan);
+    int rc = want_s ? impop_scan_plan_create(ctx, m, windows, n_windows, mask_p, mask_a, mask_b, &sp, &plan) : IMPOP_OK;
     if (rc) return rc;
     auto fail = [&](int code) {
-        impop_scan_plan_destroy(plan);
+        if (plan) impop_scan_plan_destroy(plan);
         return code;
     };
     // subset P index list and A/B flags
@@ -775,11 +779,16 @@ IMPOP_API int impop_pairwise_scan(impop_ctx *ctx, const impop_matrix *m, const i
     PW_TRY(hipMemcpyAsync(d_fb, fb.data(), n, hipMemcpyHostToDevice, ctx->stream));
     if (!ia.empty()) PW_TRY(hipMemcpyAsync(d_ia, ia.data(), ia.size() * 4, hipMemcpyHostToDevice, ctx->stream));
     if (!ib.empty()) PW_TRY(hipMemcpyAsync(d_ib, ib.data(), ib.size() * 4, hipMemcpyHostToDevice, ctx->stream));
-    rc = impop_scan_plan_launch(plan, nullptr);
-    if (rc) return fail(rc);
     std::vector<impop_window_stats> scan_host(n_windows);
-    rc = impop_scan_plan_fetch(plan, scan_host.data());
-    if (rc) return fail(rc);
+    if (want_s) {
+        rc = impop_scan_plan_launch(plan, nullptr);
+        if (rc) return fail(rc);
+        rc = impop_scan_plan_fetch(plan, scan_host.data());
+        if (rc) return fail(rc);
+    } else {
+        memset(scan_host.data(), 0, n_windows * sizeof(impop_window_stats));
+        for (uint64_t i = 0; i < n_windows; ++i) scan_host[i].n_sites = (uint32_t)(windows[i].site_end - windows[i].site_begin);
+    }
     std::vector<GramWindow> gw(chunk);
     std::vector<uint64_t> Wv(chunk), Lv(chunk);
     for (uint64_t base = 0; base < n_windows; base += chunk) {
@@ -812,12 +821,12 @@ IMPOP_API int impop_pairwise_scan(impop_ctx *ctx, const impop_matrix *m, const i
         rc = ensure_tajima_consts(ctx, nP >= 2 ? (int64_t)nP : 2);  // the cache may have been retargeted by another plan
         if (rc) return fail(rc);
         hipLaunchKernelGGL(pairwise_finalize_kernel, dim3((uint32_t)((cnt + 63) / 64)), dim3(64), 0, ctx->stream, in, cnt,
-                           nP, params->d_pi_mode, params->s_scope, ctx->d_taj, d_o);
+                           want_s ? nP : 0u, params->d_pi_mode, want_s ? params->s_scope : 0, ctx->d_taj, d_o);
         PW_TRY(hipGetLastError());
         PW_TRY(hipMemcpyAsync(out_host + base, d_o, cnt * sizeof(impop_pairwise_stats), hipMemcpyDeviceToHost, ctx->stream));
         PW_TRY(hipStreamSynchronize(ctx->stream));  // gw/Wv/Lv are reused by the next chunk
     }
 #undef PW_TRY
-    impop_scan_plan_destroy(plan);
+    if (plan) impop_scan_plan_destroy(plan);
     return IMPOP_OK;
 }

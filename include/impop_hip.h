@@ -233,7 +233,7 @@ typedef struct impop_pairwise_params {
     double threshold;        /* pica2 -t (pica2.py:175) */
     int32_t round_digits;    /* pica2 -r / h-fst -r; < 0 = none */
     int32_t d_pi_mode;       /* as impop_scan_params */
-    int32_t s_scope;
+    int32_t s_scope;         /* as impop_scan_params; 2 = S and Tajima's D not needed: skips the site scan (s_all = s_p = 0, tajima_d = NaN) */
     uint32_t fst_method;     /* 0 = h-fst.py / hud.py direct; 1 = hud.py -m grouped at `threshold` (hud.py:64-128, 235-263) */
 } impop_pairwise_params;
 typedef struct impop_pairwise_stats { /* 96 bytes */

@@ -173,8 +173,9 @@ def main():
     if need_pairwise:
         # CLI defaults of the reference: pica2.py:175 (-t 0.99), hud.py -t 0.999
         thr = (0.999 if grouped_fst else 0.99) if args.threshold is None else args.threshold
+        # the pica2 / hfst tables print neither S nor D: s_scope 2 skips the site scan of the all-pairs path
         res = bm.pairwise_scan(wins, mask_p, mask_a, mask_b, kind=args.identity, threshold=thr, round_digits=args.round_digits,
-                               fst_method=args.fst_method if grouped_fst else "direct")
+                               s_scope=2, fst_method=args.fst_method if grouped_fst else "direct")
     else:
         res = bm.scan(wins, mask_p, mask_a, mask_b)
     if world > 1:

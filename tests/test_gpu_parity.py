@@ -758,3 +758,23 @@ def test_plan_launch_is_graph_capturable():
         plan.destroy()
         bm.free()
         ctx.close()
+
+
+def test_pairwise_scan_without_site_scan(ctx):
+    """s_scope = 2: callers that print neither S nor Tajima's D skip the site scan; every other field is
+    unchanged, s_all / s_p are 0 and tajima_d is NaN."""
+    rng = np.random.default_rng(2)
+    n, W = 45, 3000
+    m01 = (rng.random((n, W)) < 0.2).astype(np.uint8)
+    bm = ctx.upload_dense(m01, keep_hap_major=True)
+    inA = np.zeros(n, np.uint8); inA[:15] = 1
+    inB = np.zeros(n, np.uint8); inB[20:40] = 1
+    wins = [(0, W, W), (10, 1500, 0), (2000, 2001, 1)]
+    a = bm.pairwise_scan(wins, None, inA, inB, threshold=0.9, round_digits=3)
+    b = bm.pairwise_scan(wins, None, inA, inB, threshold=0.9, round_digits=3, s_scope=2)
+    for k in ("pi", "pi_site", "fst", "pi_a", "pi_b", "pi_xy", "dxy", "da"):
+        x, y = a[k], b[k]
+        assert ((x == y) | (np.isnan(x) & np.isnan(y))).all(), k
+    assert (a["n_groups"] == b["n_groups"]).all() and (a["n_sites"] == b["n_sites"]).all()
+    assert (b["s_all"] == 0).all() and (b["s_p"] == 0).all() and np.isnan(b["tajima_d"]).all()
+    bm.free()

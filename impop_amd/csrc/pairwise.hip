@@ -744,28 +744,94 @@ IMPOP_API int impop_pairwise_scan(impop_ctx *ctx, const impop_matrix *m, const i
         if (fa[i] && !fb[i]) ia.push_back(i);
         if (fb[i] && !fa[i]) ib.push_back(i);
     }
-    // windows are processed in chunks so the Gram scratch stays bounded (<= ~4 GiB of 288): large chunks keep
-    // the persistent Gram grid's last, partially filled round of tasks small next to the whole launch
+    // ---- Gram cells.  I_ij is additive over disjoint site ranges, so overlapping (sliding) windows share the
+    // Gram matrices of the elementary segments between the sorted window boundaries: every site is
+    // contracted once however many windows cover it, and a window is the sum of its consecutive segments
+    // (formed on the fly by the statistics kernels, SimBatch.seg_*).  Without overlap the cells are the
+    // windows themselves.
+    struct Cell { uint64_t b, e; };
+    std::vector<Cell> cells;                                // all Gram cells, in site order when segmented
+    std::vector<uint32_t> first(n_windows, 0), count(n_windows, 0);
+    std::vector<uint64_t> ord(n_windows);
+    for (uint64_t i = 0; i < n_windows; ++i) ord[i] = i;
+    {
+        std::vector<uint64_t> cuts;
+        uint64_t win_sites = 0;
+        for (uint64_t i = 0; i < n_windows; ++i)
+            if (windows[i].site_end > windows[i].site_begin) {
+                cuts.push_back(windows[i].site_begin);
+                cuts.push_back(windows[i].site_end);
+                win_sites += windows[i].site_end - windows[i].site_begin;
+            }
+        std::sort(cuts.begin(), cuts.end());
+        cuts.erase(std::unique(cuts.begin(), cuts.end()), cuts.end());
+        auto at = [&](uint64_t s) { return (size_t)(std::lower_bound(cuts.begin(), cuts.end(), s) - cuts.begin()); };
+        std::vector<int64_t> cover(cuts.size() + 1, 0);
+        for (uint64_t i = 0; i < n_windows; ++i)
+            if (windows[i].site_end > windows[i].site_begin) {
+                cover[at(windows[i].site_begin)] += 1;
+                cover[at(windows[i].site_end)] -= 1;
+            }
+        std::vector<uint32_t> seg_before(cuts.size() + 1, 0);  // covered intervals left of cut k
+        uint64_t seg_sites = 0;
+        int64_t depth = 0;
+        std::vector<Cell> segs;
+        for (size_t k = 0; k + 1 < cuts.size(); ++k) {
+            seg_before[k] = (uint32_t)segs.size();
+            depth += cover[k];
+            if (depth > 0) {
+                segs.push_back({cuts[k], cuts[k + 1]});
+                seg_sites += cuts[k + 1] - cuts[k];
+            }
+        }
+        if (!cuts.empty()) seg_before[cuts.size() - 1] = (uint32_t)segs.size();
+        if (seg_sites * 20 < win_sites * 19 && segs.size() < 0xFFFFFFF0ull) {  // >= 5 % of the contraction is shared
+            cells.swap(segs);
+            for (uint64_t i = 0; i < n_windows; ++i)
+                if (windows[i].site_end > windows[i].site_begin) {
+                    first[i] = seg_before[at(windows[i].site_begin)];
+                    count[i] = seg_before[at(windows[i].site_end)] - first[i];
+                }
+            std::stable_sort(ord.begin(), ord.end(), [&](uint64_t a, uint64_t b) {
+                const bool ea = count[a] == 0, eb = count[b] == 0;  // empty windows last
+                return ea != eb ? eb : (!ea && first[a] < first[b]);
+            });
+        } else {
+            if (n_windows >= 0xFFFFFFF0ull) {
+                set_error("impop_pairwise_scan: too many windows");
+                return fail(IMPOP_E_INVALID);
+            }
+            cells.resize(n_windows);
+            for (uint64_t i = 0; i < n_windows; ++i) {
+                cells[i] = {windows[i].site_begin, windows[i].site_end};
+                first[i] = (uint32_t)i;
+                count[i] = 1;
+            }
+        }
+    }
+    // Chunks of consecutive (in `ord`) windows whose cells fit the Gram scratch (<= ~4 GiB of 288): large
+    // chunks keep the persistent Gram grid's last, partially filled round of tasks small next to the launch
     const size_t gram_bytes = (size_t)ld * ld * 4;
-    uint64_t chunk = (4ull << 30) / gram_bytes;
-    if (chunk < 1) chunk = 1;
-    if (chunk > 4096) chunk = 4096;
-    if (chunk > n_windows) chunk = n_windows;
+    uint64_t cap = (4ull << 30) / gram_bytes;
+    if (cap < 1) cap = 1;
+    if (cap > 4096) cap = 4096;
     void *d = nullptr;
-    const size_t need = 4096 + chunk * (gram_bytes + sizeof(GramWindow) + 16 + sizeof(Pica2Out) + sizeof(HfstOut) +
-                                        sizeof(impop_window_stats) + sizeof(impop_pairwise_stats) + 2048) +
+    const size_t need = 4096 + cap * (gram_bytes + sizeof(GramWindow) + 24 + sizeof(Pica2Out) + sizeof(HfstOut) +
+                                      sizeof(impop_window_stats) + sizeof(impop_pairwise_stats) + 2560) +
                         (size_t)n * 16 + 8192;
     rc = ctx_scratch(ctx, need, &d);
     if (rc) return fail(rc);
     Carve2 cv(d);
-    int32_t *d_g = cv.take<int32_t>(chunk * (size_t)ld * ld);
-    GramWindow *d_w = cv.take<GramWindow>(chunk);
-    uint64_t *d_W = cv.take<uint64_t>(chunk);
-    uint64_t *d_L = cv.take<uint64_t>(chunk);
-    Pica2Out *d_p = cv.take<Pica2Out>(chunk);
-    HfstOut *d_h = cv.take<HfstOut>(chunk);
-    impop_window_stats *d_s = cv.take<impop_window_stats>(chunk);
-    impop_pairwise_stats *d_o = cv.take<impop_pairwise_stats>(chunk);
+    int32_t *d_g = cv.take<int32_t>(cap * (size_t)ld * ld);
+    GramWindow *d_w = cv.take<GramWindow>(cap);
+    uint64_t *d_W = cv.take<uint64_t>(cap);
+    uint64_t *d_L = cv.take<uint64_t>(cap);
+    uint32_t *d_first = cv.take<uint32_t>(cap);
+    uint32_t *d_count = cv.take<uint32_t>(cap);
+    Pica2Out *d_p = cv.take<Pica2Out>(cap);
+    HfstOut *d_h = cv.take<HfstOut>(cap);
+    impop_window_stats *d_s = cv.take<impop_window_stats>(cap);
+    impop_pairwise_stats *d_o = cv.take<impop_pairwise_stats>(cap);
     uint32_t *d_idx = cv.take<uint32_t>(n ? n : 1);
     uint8_t *d_fa = cv.take<uint8_t>(n ? n : 1);
     uint8_t *d_fb = cv.take<uint8_t>(n ? n : 1);
@@ -789,27 +855,61 @@ IMPOP_API int impop_pairwise_scan(impop_ctx *ctx, const impop_matrix *m, const i
         memset(scan_host.data(), 0, n_windows * sizeof(impop_window_stats));
         for (uint64_t i = 0; i < n_windows; ++i) scan_host[i].n_sites = (uint32_t)(windows[i].site_end - windows[i].site_begin);
     }
-    std::vector<GramWindow> gw(chunk);
-    std::vector<uint64_t> Wv(chunk), Lv(chunk);
-    for (uint64_t base = 0; base < n_windows; base += chunk) {
-        const uint64_t cnt = std::min<uint64_t>(chunk, n_windows - base);
-        uint64_t max_sites = 0;
-        for (uint64_t k = 0; k < cnt; ++k) {
-            max_sites = std::max<uint64_t>(max_sites, windows[base + k].site_end - windows[base + k].site_begin);
-            gw[k] = {windows[base + k].site_begin, windows[base + k].site_end};
-            Wv[k] = windows[base + k].site_end - windows[base + k].site_begin;
-            Lv[k] = windows[base + k].seq_len;
+    std::vector<GramWindow> gw(cap);
+    std::vector<uint64_t> Wv(cap), Lv(cap);
+    std::vector<uint32_t> fv(cap), cvv(cap);
+    std::vector<impop_window_stats> sv(cap);
+    std::vector<impop_pairwise_stats> ov(cap);
+    for (uint64_t base = 0; base < n_windows;) {
+        // windows ord[base .. base+cnt): their cells are [c_lo, c_hi)
+        uint64_t cnt = 0;
+        uint32_t c_lo = 0, c_hi = 0;
+        bool have = false;
+        while (base + cnt < n_windows && cnt < cap) {
+            const uint64_t wdx = ord[base + cnt];
+            if (count[wdx]) {
+                const uint32_t lo = have ? std::min(c_lo, first[wdx]) : first[wdx];
+                const uint32_t hi = have ? std::max(c_hi, first[wdx] + count[wdx]) : first[wdx] + count[wdx];
+                if ((uint64_t)(hi - lo) > cap) {
+                    if (cnt == 0) {
+                        set_error("impop_pairwise_scan: window %llu spans %u segments, more than the %llu Gram matrices that fit "
+                                  "the scratch", (unsigned long long)wdx, count[wdx], (unsigned long long)cap);
+                        return fail(IMPOP_E_INVALID);
+                    }
+                    break;
+                }
+                c_lo = lo; c_hi = hi; have = true;
+            }
+            ++cnt;
         }
-        PW_TRY(hipMemcpyAsync(d_w, gw.data(), cnt * sizeof(GramWindow), hipMemcpyHostToDevice, ctx->stream));
+        const uint32_t n_cells = have ? c_hi - c_lo : 0;
+        uint64_t max_sites = 0;
+        for (uint32_t c = 0; c < n_cells; ++c) {
+            gw[c] = {cells[c_lo + c].b, cells[c_lo + c].e};
+            max_sites = std::max<uint64_t>(max_sites, cells[c_lo + c].e - cells[c_lo + c].b);
+        }
+        for (uint64_t k = 0; k < cnt; ++k) {
+            const uint64_t wdx = ord[base + k];
+            Wv[k] = windows[wdx].site_end - windows[wdx].site_begin;
+            Lv[k] = windows[wdx].seq_len;
+            fv[k] = count[wdx] ? first[wdx] - c_lo : 0;
+            cvv[k] = count[wdx];
+            sv[k] = scan_host[wdx];
+        }
+        if (n_cells) PW_TRY(hipMemcpyAsync(d_w, gw.data(), n_cells * sizeof(GramWindow), hipMemcpyHostToDevice, ctx->stream));
         PW_TRY(hipMemcpyAsync(d_W, Wv.data(), cnt * 8, hipMemcpyHostToDevice, ctx->stream));
         PW_TRY(hipMemcpyAsync(d_L, Lv.data(), cnt * 8, hipMemcpyHostToDevice, ctx->stream));
-        PW_TRY(hipMemcpyAsync(d_s, scan_host.data() + base, cnt * sizeof(impop_window_stats), hipMemcpyHostToDevice,
-                              ctx->stream));
-        rc = launch_gram(ctx, m, d_w, (uint32_t)cnt, d_g, max_sites);
-        if (rc) return fail(rc);
+        PW_TRY(hipMemcpyAsync(d_first, fv.data(), cnt * 4, hipMemcpyHostToDevice, ctx->stream));
+        PW_TRY(hipMemcpyAsync(d_count, cvv.data(), cnt * 4, hipMemcpyHostToDevice, ctx->stream));
+        PW_TRY(hipMemcpyAsync(d_s, sv.data(), cnt * sizeof(impop_window_stats), hipMemcpyHostToDevice, ctx->stream));
+        if (n_cells) {
+            rc = launch_gram(ctx, m, d_w, n_cells, d_g, max_sites);
+            if (rc) return fail(rc);
+        }
         SimBatch b{};
         b.gram = d_g; b.stride = (uint64_t)ld * ld; b.ld = ld; b.n = n; b.W = d_W; b.kind = params->identity_kind;
         b.round_digits = params->round_digits < 0 ? -1 : params->round_digits;
+        b.seg_first = d_first; b.seg_count = d_count;
         rc = launch_pica2(ctx, b, cnt, mask_p ? d_idx : nullptr, nP, params->threshold, d_L, d_p, nullptr);
         if (rc) return fail(rc);
         if (params->fst_method == 1)
@@ -823,8 +923,10 @@ IMPOP_API int impop_pairwise_scan(impop_ctx *ctx, const impop_matrix *m, const i
         hipLaunchKernelGGL(pairwise_finalize_kernel, dim3((uint32_t)((cnt + 63) / 64)), dim3(64), 0, ctx->stream, in, cnt,
                            want_s ? nP : 0u, params->d_pi_mode, want_s ? params->s_scope : 0, ctx->d_taj, d_o);
         PW_TRY(hipGetLastError());
-        PW_TRY(hipMemcpyAsync(out_host + base, d_o, cnt * sizeof(impop_pairwise_stats), hipMemcpyDeviceToHost, ctx->stream));
-        PW_TRY(hipStreamSynchronize(ctx->stream));  // gw/Wv/Lv are reused by the next chunk
+        PW_TRY(hipMemcpyAsync(ov.data(), d_o, cnt * sizeof(impop_pairwise_stats), hipMemcpyDeviceToHost, ctx->stream));
+        PW_TRY(hipStreamSynchronize(ctx->stream));  // the staging vectors are reused by the next chunk
+        for (uint64_t k = 0; k < cnt; ++k) out_host[ord[base + k]] = ov[k];
+        base += cnt;
     }
 #undef PW_TRY
     if (plan) impop_scan_plan_destroy(plan);

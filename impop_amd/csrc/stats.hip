@@ -132,7 +132,7 @@ __global__ __launch_bounds__(ST) void hfst_kernel(SimBatch batch, const uint8_t 
     if (cached) {
         for (uint32_t i = tid; i < n; i += ST) {
             cls_l[i] = (uint8_t)cls_of(i);
-            if (S.gram) diag_l[i] = S.gram[(uint64_t)i * S.ld + i];
+            if (S.gram) diag_l[i] = (int32_t)gram_at(S, i, i);
         }
         if (S.gram) S.diag = diag_l;
     }

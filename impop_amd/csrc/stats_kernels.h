@@ -17,6 +17,11 @@ struct SimBatch {
     const uint64_t *W;     // per-problem site count (gram mode)
     int kind;
     int round_digits;
+    // gram mode, optional: problem p is the SUM of the consecutive Gram matrices seg_first[p] .. +seg_count[p]
+    // (elementary segments shared by overlapping windows: I_ij is additive over disjoint site ranges);
+    // nullptr = exactly one matrix per problem, at index p
+    const uint32_t *seg_first;
+    const uint32_t *seg_count;
 };
 
 struct SimView {
@@ -32,6 +37,8 @@ struct SimView {
     const double *tbl;
     uint32_t tbl_n;
     const int32_t *diag;  // optional LDS copy of the Gram diagonal a_i (else read from `gram`)
+    uint32_t nseg;        // Gram matrices to add up (gram mode)
+    uint64_t seg_stride;  // elements between them
 };
 
 constexpr uint32_t SIM_TBL_N = 4096;
@@ -56,7 +63,14 @@ __device__ inline void sim_table_fill(SimView &S, double *lds_tbl, uint32_t n_th
 __device__ inline SimView sim_view(const SimBatch &b, uint64_t p) {
     SimView v;
     v.dense = b.dense ? b.dense + p * b.stride : nullptr;
-    v.gram = b.gram ? b.gram + p * b.stride : nullptr;
+    v.nseg = 1;
+    v.seg_stride = b.stride;
+    if (b.gram && b.seg_first) {
+        v.gram = b.gram + (uint64_t)b.seg_first[p] * b.stride;
+        v.nseg = b.seg_count[p];
+    } else {
+        v.gram = b.gram ? b.gram + p * b.stride : nullptr;
+    }
     v.ld = b.ld;
     v.W = b.W ? b.W[p] : 0;
     v.kind = b.kind;
@@ -67,6 +81,14 @@ __device__ inline SimView sim_view(const SimBatch &b, uint64_t p) {
     return v;
 }
 
+// Gram entry (i, j) of a problem = sum over its segments
+__device__ inline int64_t gram_at(const SimView &S, uint32_t i, uint32_t j) {
+    const int32_t *g = S.gram + (uint64_t)i * S.ld + j;
+    int64_t v = 0;
+    for (uint32_t k = 0; k < S.nseg; ++k) v += g[k * S.seg_stride];
+    return v;
+}
+
 // identity of the unordered pair {i, j}; NaN = pair absent (pica2.py:85-87 keying)
 __device__ inline double sim_get(const SimView &S, uint32_t i, uint32_t j) {
     if (i > j) { const uint32_t t = i; i = j; j = t; }
@@ -74,9 +96,9 @@ __device__ inline double sim_get(const SimView &S, uint32_t i, uint32_t j) {
     if (S.dense) {
         v = S.dense[(uint64_t)i * S.ld + j];
     } else {
-        const int64_t I = S.gram[(uint64_t)i * S.ld + j];
-        const int64_t ai = S.diag ? S.diag[i] : S.gram[(uint64_t)i * S.ld + i];
-        const int64_t aj = S.diag ? S.diag[j] : S.gram[(uint64_t)j * S.ld + j];
+        const int64_t I = gram_at(S, i, j);
+        const int64_t ai = S.diag ? S.diag[i] : gram_at(S, i, i);
+        const int64_t aj = S.diag ? S.diag[j] : gram_at(S, j, j);
         if (S.kind == IMPOP_IDENTITY_MATCH) {
             const int64_t H = ai + aj - 2 * I;
             if ((uint64_t)H < S.tbl_n) return S.tbl[H];  // memoised (already rounded)

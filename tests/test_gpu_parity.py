@@ -778,3 +778,33 @@ def test_pairwise_scan_without_site_scan(ctx):
     assert (a["n_groups"] == b["n_groups"]).all() and (a["n_sites"] == b["n_sites"]).all()
     assert (b["s_all"] == 0).all() and (b["s_p"] == 0).all() and np.isnan(b["tajima_d"]).all()
     bm.free()
+
+
+def test_pairwise_scan_overlapping_windows_share_segments(ctx, oracle):
+    """Sliding windows: the all-pairs path contracts every elementary segment once and forms a window as
+    the sum of its segments' Gram matrices.  Records must equal those of the same windows scanned one by
+    one (no sharing), in the caller's order, for shuffled, nested, duplicate and empty windows."""
+    rng = np.random.default_rng(33)
+    n, W = 70, 12000
+    anc = rng.integers(0, 2, size=W, dtype=np.uint8)
+    f = np.repeat(anc[None, :], 4, axis=0) ^ (rng.random((4, W)) < 0.02).astype(np.uint8)
+    m01 = f[rng.integers(0, 4, size=n)] ^ (rng.random((n, W)) < 0.001).astype(np.uint8)
+    bm = ctx.upload_dense(m01, keep_hap_major=True)
+    inA = np.zeros(n, np.uint8); inA[:25] = 1
+    inB = np.zeros(n, np.uint8); inB[30:60] = 1
+    wins = [(s, min(s + 2000, W), 2000) for s in range(0, W - 500, 500)]          # window = 4 x step
+    wins += [(100, 11000, 0), (3000, 3001, 1), (5000, 5000, 0), (2500, 4500, 2000), (2500, 4500, 777), (0, W, W)]
+    order = rng.permutation(len(wins))
+    wins = [wins[i] for i in order]
+    for kw in (dict(threshold=0.995, round_digits=4), dict(threshold=0.99, kind="dice"), dict(threshold=0.995, fst_method="grouped")):
+        shared = bm.pairwise_scan(wins, None, inA, inB, **kw)
+        for k, w in enumerate(wins):
+            single = bm.pairwise_scan([w], None, inA, inB, **kw)[0]
+            assert shared[k].tobytes() == single.tobytes(), (kw, w)
+    # one window against the oracle directly
+    s0, s1, L = 1500, 3500, 2000
+    sim = oracle.identity(oracle.pairwise_counts(oracle.pack_hap_major(m01), n, s0, s1), s1 - s0, 0)
+    r = bm.pairwise_scan([(s, s + 2000, 2000) for s in range(0, 4000, 500)], None, inA, inB, threshold=0.995, round_digits=4)[3]
+    pi, ps, _, G = oracle.pica2(sim, 0.995, L, 4)
+    assert rel_close(float(r["pi"]), pi, REL, 1e-300) and int(r["n_groups"]) == G
+    bm.free()

@@ -855,6 +855,16 @@ IMPOP_API int impop_pairwise_scan(impop_ctx *ctx, const impop_matrix *m, const i
         memset(scan_host.data(), 0, n_windows * sizeof(impop_window_stats));
         for (uint64_t i = 0; i < n_windows; ++i) scan_host[i].n_sites = (uint32_t)(windows[i].site_end - windows[i].site_begin);
     }
+    // even out the chunks: a total slightly above the capacity would otherwise leave a last chunk of a few
+    // windows whose single-workgroup epilogue kernels cost their full latency
+    uint64_t cell_limit = cap;
+    if (cells.size() > cap) {
+        uint32_t widest = 1;
+        for (uint64_t i = 0; i < n_windows; ++i) widest = std::max(widest, count[i]);
+        uint64_t n_chunks = (cells.size() + cap - 1) / cap;
+        if ((cells.size() + n_chunks - 1) / n_chunks + widest > cap) ++n_chunks;  // neighbours re-contract up to `widest` cells
+        cell_limit = std::min<uint64_t>(cap, (cells.size() + n_chunks - 1) / n_chunks + widest);
+    }
     std::vector<GramWindow> gw(cap);
     std::vector<uint64_t> Wv(cap), Lv(cap);
     std::vector<uint32_t> fv(cap), cvv(cap);
@@ -865,12 +875,12 @@ IMPOP_API int impop_pairwise_scan(impop_ctx *ctx, const impop_matrix *m, const i
         uint64_t cnt = 0;
         uint32_t c_lo = 0, c_hi = 0;
         bool have = false;
-        while (base + cnt < n_windows && cnt < cap) {
+        while (base + cnt < n_windows && cnt < cell_limit) {
             const uint64_t wdx = ord[base + cnt];
             if (count[wdx]) {
                 const uint32_t lo = have ? std::min(c_lo, first[wdx]) : first[wdx];
                 const uint32_t hi = have ? std::max(c_hi, first[wdx] + count[wdx]) : first[wdx] + count[wdx];
-                if ((uint64_t)(hi - lo) > cap) {
+                if ((uint64_t)(hi - lo) > (cnt == 0 ? cap : cell_limit)) {
                     if (cnt == 0) {
                         set_error("impop_pairwise_scan: window %llu spans %u segments, more than the %llu Gram matrices that fit "
                                   "the scratch", (unsigned long long)wdx, count[wdx], (unsigned long long)cap);

@@ -4,7 +4,7 @@ exchange is ONE all-gather of fixed-size per-window records (RCCL over xGMI with
 reduction and no data-path collective."""
 from __future__ import annotations
 
-from typing import Callable, Optional, Tuple
+from typing import Callable, Tuple
 
 import numpy as np
 

@@ -6,7 +6,7 @@ all arithmetic runs in libimpop_hip.so on the GPU.
 from __future__ import annotations
 
 import ctypes as C
-from typing import Iterable, Optional, Sequence
+from typing import Optional
 
 import numpy as np
 

@@ -10,7 +10,7 @@ keys  bits      uint64 [n_hap, ceil(n_site/64)]   hap-major bit rows (bit s&63 o
 """
 from __future__ import annotations
 
-from dataclasses import dataclass, field
+from dataclasses import dataclass
 from typing import List, Optional
 
 import numpy as np

@@ -5,7 +5,7 @@ from __future__ import annotations
 import csv
 import os
 import sys
-from typing import Dict, Iterable, List, Sequence, Set, Tuple
+from typing import Dict, Sequence, Set, Tuple
 
 import numpy as np
 

@@ -1,5 +1,4 @@
 """CPU: presence-matrix extractors and the matrix container (SURVEY §8f-2/3 host side)."""
-import numpy as np
 
 import impop_amd
 from impop_amd import extract, matrixio

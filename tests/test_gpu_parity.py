@@ -1,7 +1,6 @@
 """GPU parity tests (run with -m gpu on an MI355X): the HIP engine, called through the C ABI,
 against the CPU oracle on the same seeded inputs and against the goldens captured from the
 real reference.  Integers bit-exact; pi / Fst / D within 1e-9 relative (north_star)."""
-import math
 import random
 
 import numpy as np

@@ -1,10 +1,8 @@
 """CPU tests of the host layer: name handling, .sim ingest and its error texts, the C-ABI
 library loads and exports every declared symbol (no compute without a GPU)."""
-import io
 import os
 import re
 import subprocess
-import sys
 
 import numpy as np
 import pytest

@@ -1,7 +1,5 @@
 """CPU: the native .sim parser (impop_sim_parse, host C++) against the Python readers that
 mirror the reference line by line, on clean, ragged and hostile files."""
-import io
-import os
 import random
 
 import numpy as np

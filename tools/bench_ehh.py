@@ -2,7 +2,6 @@
 """Timing point for impop_ehh: n-hap synthetic founder matrix, one 50 kb window, both directions."""
 import argparse, json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import numpy as np
 import impop_amd
 
 ap = argparse.ArgumentParser()

@@ -9,7 +9,6 @@ IMPOP_SCAN_MIN_WAVES) x the runtime tile size.  Each variant is its own .so, loa
 side with ctypes (RTLD_LOCAL), timed with the library's own HIP events, rounds interleaved.
 """
 import ctypes as C
-import itertools
 import json
 import os
 import statistics

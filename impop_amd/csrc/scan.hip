@@ -635,7 +635,7 @@ IMPOP_API int impop_scan_plan_create(impop_ctx *ctx, const impop_matrix *m, cons
     p->ctx = ctx; p->m = m; p->n_windows = n_windows;
     m->users++;
     p->d_pi_mode = prm.d_pi_mode; p->s_scope = prm.s_scope;
-    const uint32_t n = m->g.n_hap, wps = m->g.wps;
+    const uint32_t wps = m->g.wps;
     plan_set_masks(p, mask_p, mask_a, mask_b);
 
     std::vector<ScanTile> tiles;

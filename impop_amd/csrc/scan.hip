@@ -105,9 +105,12 @@ struct LaneAcc32 {
     uint32_t q_p = 0, q_a = 0, q_b = 0, q_ab = 0;
 };
 
+// One site per lane.  No validity test here: lanes outside the tile had their words zeroed by the caller
+// (only the first / last block of a tile can be partial), and all-zero words add nothing to any counter.
+// Segregating test 0 < c < n as ONE unsigned compare: (c - 1) < (n - 1)  (false for n = 0 or 1 as well).
 template <int WPS, bool SUBSET_P>
 __device__ __forceinline__ void site_accumulate(const uint32_t (&w)[WPS], const MaskArgs<WPS> &mk, const PopSizes &ps,
-                                                bool valid, LaneAcc32 &acc) {
+                                                LaneAcc32 &acc) {
     uint32_t c = 0, cP = 0, cA = 0, cB = 0;
 #pragma unroll
     for (int k = 0; k < WPS; ++k) {
@@ -117,16 +120,15 @@ __device__ __forceinline__ void site_accumulate(const uint32_t (&w)[WPS], const 
         cB += __popc(w[k] & mk.b[k]);
     }
     if (!SUBSET_P) cP = c;
-    if (valid) {
-        acc.s_all += (c != 0 && c != ps.n);
-        acc.s_p += (cP != 0 && cP != ps.nP);
-        acc.s_a += (cA != 0 && cA != ps.nA);
-        acc.s_b += (cB != 0 && cB != ps.nB);
-        acc.q_p += __umul24(cP, ps.nP - cP);
-        acc.q_a += __umul24(cA, ps.nA - cA);
-        acc.q_b += __umul24(cB, ps.nB - cB);
-        acc.q_ab += __umul24(cA, ps.nB - cB) + __umul24(cB, ps.nA - cA);
-    }
+    acc.s_all += (c - 1u) < (ps.n - 1u);
+    acc.s_p += (cP - 1u) < (ps.nP - 1u);
+    acc.s_a += (cA - 1u) < (ps.nA - 1u);
+    acc.s_b += (cB - 1u) < (ps.nB - 1u);
+    const uint32_t rA = ps.nA - cA, rB = ps.nB - cB;
+    acc.q_p += __umul24(cP, ps.nP - cP);
+    acc.q_a += __umul24(cA, rA);
+    acc.q_b += __umul24(cB, rB);
+    acc.q_ab += __umul24(cA, rB) + __umul24(cB, rA);
 }
 
 __device__ __forceinline__ void tile_reduce_store(LaneAcc &acc, TilePartial *out) {
@@ -170,6 +172,18 @@ __global__ __launch_bounds__(256, IMPOP_SCAN_MIN_WAVES) void scan_tiles_kernel(c
     uint64_t b = b0 + wave;
     constexpr int G = (WPS + 3) / 4;
     constexpr int U = IMPOP_SCAN_UNROLL > 0 ? IMPOP_SCAN_UNROLL : (G >= 3 ? 2 : G == 2 ? 4 : 8);
+    // Only the first and the last block of a tile can be partial: lanes before `lo` in block b0 and from `hi`
+    // on in block b1-1 get all-zero words (wave-uniform branch, taken for those two blocks only); interior
+    // blocks carry no validity arithmetic and no branch, so all U loads of an iteration are in flight together.
+    const uint32_t lo = (uint32_t)(t.site_begin - (b0 << 6));
+    const uint32_t hi = (uint32_t)(t.site_end - ((b1 - 1) << 6));  // 1..64
+    auto trim = [&](uint32_t (&w)[WPS], uint64_t blk) {
+        if ((blk == b0 && lo != 0) | (blk == b1 - 1 && hi != 64)) {
+            const bool keep = lane >= (blk == b0 ? lo : 0u) && lane < (blk == b1 - 1 ? hi : 64u);
+#pragma unroll
+            for (int k = 0; k < WPS; ++k) w[k] = keep ? w[k] : 0u;
+        }
+    };
     // U blocks per iteration: U*ceil(WPS/4) independent 1 KiB wave loads in flight per wave
     for (; b + 4 * (U - 1) < b1; b += 4 * U) {
         uint32_t w[U][WPS];
@@ -177,15 +191,15 @@ __global__ __launch_bounds__(256, IMPOP_SCAN_MIN_WAVES) void scan_tiles_kernel(c
         for (int u = 0; u < U; ++u) load_site<WPS>(sb + (b + 4 * u) * (64ull * WPS), lane, w[u]);
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const uint64_t s = (b + 4 * u) * 64 + lane;
-            site_accumulate<WPS, SUBSET_P>(w[u], mk, ps, s >= t.site_begin && s < t.site_end, acc);
+            trim(w[u], b + 4 * u);
+            site_accumulate<WPS, SUBSET_P>(w[u], mk, ps, acc);
         }
     }
     for (; b < b1; b += 4) {
         uint32_t w0[WPS];
         load_site<WPS>(sb + b * (64ull * WPS), lane, w0);
-        const uint64_t s0 = b * 64 + lane;
-        site_accumulate<WPS, SUBSET_P>(w0, mk, ps, s0 >= t.site_begin && s0 < t.site_end, acc);
+        trim(w0, b);
+        site_accumulate<WPS, SUBSET_P>(w0, mk, ps, acc);
     }
     LaneAcc wide;
     wide.s_all = acc.s_all; wide.s_p = acc.s_p; wide.s_a = acc.s_a; wide.s_b = acc.s_b;

@@ -533,8 +533,11 @@ static void build_tiles(const impop_window *windows, uint64_t n_windows, uint32_
         // tiles are cut on 64-site block boundaries of the matrix so interior tiles read whole blocks
         uint64_t s = cuts[k];
         const uint64_t e = cuts[k + 1];
+        // equal shares: a 781-block segment under a 512-block limit becomes 391 + 390 blocks, not 512 + 269
+        const uint64_t nblk = (e + 63) / 64 - s / 64, n_parts = (nblk + tile_blocks - 1) / tile_blocks;
+        const uint64_t per = (nblk + n_parts - 1) / n_parts;
         while (s < e) {
-            uint64_t t_end = ((s / 64) + tile_blocks) * 64;  // block-aligned end
+            uint64_t t_end = ((s / 64) + per) * 64;  // block-aligned end
             if (t_end > e) t_end = e;
             tiles.push_back({s, t_end});
             bytes_streamed += ((t_end + 63) / 64 - s / 64) * 64ull * wps * 4ull;
@@ -578,6 +581,17 @@ struct impop_scan_plan {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;  // pool, one pair per timed launch
     size_t events_used = 0;
 };
+
+// Default tile: ~256 KB of matrix per workgroup, but never so large that a small job leaves CUs without
+// work (>= 16 tiles per CU wanted), and never below the 32 blocks the kernel was tuned with.
+static uint32_t default_tile_blocks(const impop_ctx *ctx, const impop_matrix *m, const impop_window *windows, uint64_t n_windows) {
+    const uint32_t by_bytes = std::max<uint32_t>(32, 1024 / m->g.wps);
+    uint64_t blocks = 0;
+    for (uint64_t i = 0; i < n_windows; ++i) blocks += (windows[i].site_end - windows[i].site_begin + 63) / 64;
+    if (m->compact && blocks > m->g.n_block) blocks = m->g.n_block;
+    const uint64_t by_parallelism = blocks / (16ull * (uint64_t)(ctx->n_cu > 0 ? ctx->n_cu : 256));
+    return (uint32_t)std::max<uint64_t>(32, std::min<uint64_t>(by_bytes, by_parallelism));
+}
 
 // subset masks of a plan; the overlap of A and B is removed from both (h-fst.py:181-185)
 static void plan_set_masks(impop_scan_plan *p, const uint64_t *mask_p, const uint64_t *mask_a, const uint64_t *mask_b) {
@@ -633,7 +647,10 @@ IMPOP_API int impop_scan_plan_create(impop_ctx *ctx, const impop_matrix *m, cons
     }
     REQUIRE(prm.d_pi_mode >= 0 && prm.d_pi_mode <= 2, "impop_scan_params.d_pi_mode must be 0..2");
     REQUIRE(prm.s_scope == 0 || prm.s_scope == 1, "impop_scan_params.s_scope must be 0 or 1");
-    uint32_t tile_blocks = prm.tile_blocks ? prm.tile_blocks : 32;
+    // default tile: ~160 KB of matrix per workgroup.  With few haplotypes a 32-block tile is only a few KB and
+    // the per-workgroup costs (launch, LDS reduction, partial store) bound the kernel instead of HBM:
+    // n = 32 ran at 2.6 TB/s with 32-block tiles and 5.0 TB/s with whole-window tiles
+    uint32_t tile_blocks = prm.tile_blocks ? prm.tile_blocks : default_tile_blocks(ctx, m, windows, n_windows);
     REQUIRE(tile_blocks <= 4096, "impop_scan_params.tile_blocks too large");
     if (m->g.wps > 16 && tile_blocks > 4 * SB_MAX) tile_blocks = 4 * SB_MAX;  // the any-n kernel keeps <= 8 blocks per wave in registers
     for (uint64_t i = 0; i < n_windows; ++i) {
@@ -877,7 +894,8 @@ IMPOP_API int impop_scan_multi(impop_ctx *ctx, const impop_matrix *m, const impo
     {
         std::vector<impop_window> mapped;
         map_windows(m, windows, n_windows, mapped);
-        build_tiles(mapped.data(), n_windows, 32, wps, tiles, wd, bytes);
+        build_tiles(mapped.data(), n_windows, default_tile_blocks(ctx, m, windows, n_windows), wps, tiles, wd, bytes);
+
         for (uint64_t i = 0; m->compact && i < n_windows; ++i) wd[i].n_sites = windows[i].site_end - windows[i].site_begin;
     }
     REQUIRE(tiles.size() < 0x7FFFFFFFull, "impop_scan_multi: too many tiles");

@@ -111,20 +111,28 @@ __global__ __launch_bounds__(ST) void pica2_kernel(SimBatch batch, const uint32_
 // counts for pi_A, pi_B or Dxy according to the classes of its two ends.  Classes, the Gram diagonal
 // and the identity memo live in LDS.  (Before: one thread per row walking all columns, every load its
 // own cache line: 0.82 us per 465-haplotype window, a third of the all-pairs path.)
-constexpr uint32_t HF_LDS_N = 4096;  // problems up to this many sequences cache class + diagonal in LDS
+// Occupancy is what this kernel lives on: a wave walks its rows one after the other and every Gram row
+// comes from HBM (written a whole launch ago), so the SIMDs need many resident waves to hide that latency.
+// Measured on 4096 x 10 kb windows (tools/time_epilogue.py): with a 32 KB memo + 20 KB of class / diagonal
+// arrays (3 workgroups per CU) the pair loop cost 0.30 us per window; with an 8 KB memo and arrays sized by
+// n (8 workgroups per CU) 0.15 us; issuing the loads of 8-32 column chunks ahead of their use did not help
+// (more registers, fewer waves).  Identities of pairs further apart than the memo reaches are computed
+// directly.
+constexpr uint32_t HF_LDS_N = 4096;  // problems up to this many sequences keep class + Gram diagonal in LDS
 __global__ __launch_bounds__(ST) void hfst_kernel(SimBatch batch, const uint8_t *__restrict__ in_a,
                                                   const uint8_t *__restrict__ in_b, const uint64_t *__restrict__ seq_len,
                                                   HfstOut *__restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char hf_lds[];  // diag[n] int32 | cls[n] u8 (n <= HF_LDS_N)
     __shared__ double shd[ST / 64];
     __shared__ uint64_t shu[ST / 64];
     __shared__ double sim_tbl[SIM_TBL_N];
-    __shared__ int32_t diag_l[HF_LDS_N];
-    __shared__ uint8_t cls_l[HF_LDS_N];
     const uint64_t prob = blockIdx.x;
     SimView S = sim_view(batch, prob);
     sim_table_fill(S, sim_tbl, ST);
     const uint32_t n = batch.n, tid = threadIdx.x;
     const bool cached = n <= HF_LDS_N;
+    int32_t *diag_l = reinterpret_cast<int32_t *>(hf_lds);
+    uint8_t *cls_l = hf_lds + (size_t)n * 4;
     auto cls_of = [&](uint32_t i) -> uint32_t {  // 1 = A only, 2 = B only, 0 = neither or both (h-fst.py:181-185)
         const bool a = in_a[i], b = in_b[i];
         return (a && !b) ? 1u : (b && !a) ? 2u : 0u;
@@ -396,7 +404,8 @@ int launch_hfst(impop_ctx *ctx, const SimBatch &b, uint64_t n_problems, const ui
                 const uint64_t *d_seq_len, HfstOut *d_out) {
     if (!n_problems) return IMPOP_OK;
     REQUIRE(n_problems < 0x7FFFFFFFull, "hfst: too many problems");
-    hipLaunchKernelGGL(hfst_kernel, dim3((uint32_t)n_problems), dim3(ST), 0, ctx->stream, b, d_in_a, d_in_b, d_seq_len,
+    const size_t lds = b.n <= HF_LDS_N ? (size_t)b.n * 5 + 16 : 16;
+    hipLaunchKernelGGL(hfst_kernel, dim3((uint32_t)n_problems), dim3(ST), lds, ctx->stream, b, d_in_a, d_in_b, d_seq_len,
                        d_out);
     HIP_TRY(hipGetLastError());
     return IMPOP_OK;

@@ -41,7 +41,7 @@ struct SimView {
     uint64_t seg_stride;  // elements between them
 };
 
-constexpr uint32_t SIM_TBL_N = 4096;
+constexpr uint32_t SIM_TBL_N = 1024;  // 8 KB: LDS footprint decides the occupancy of the epilogue kernels
 
 __device__ inline double match_identity(uint64_t W, int64_t H, int round_digits) {
     double v = W ? (double)((int64_t)W - H) / (double)W : 1.0;
@@ -89,25 +89,27 @@ __device__ inline int64_t gram_at(const SimView &S, uint32_t i, uint32_t j) {
     return v;
 }
 
+// identity from the Gram counts of a pair: I = shared sites, ai / aj = sites carried by i / by j
+__device__ inline double sim_from_gram(const SimView &S, int64_t I, int64_t ai, int64_t aj) {
+    double v;
+    if (S.kind == IMPOP_IDENTITY_MATCH) {
+        const int64_t H = ai + aj - 2 * I;
+        if ((uint64_t)H < S.tbl_n) return S.tbl[H];  // memoised (already rounded)
+        v = S.W ? (double)((int64_t)S.W - H) / (double)S.W : 1.0;
+    } else {
+        const int64_t d = ai + aj;
+        v = d ? (double)(2 * I) / (double)d : 1.0;
+    }
+    if (S.round_digits >= 0) v = py_round(v, S.round_digits);
+    return v;
+}
+
 // identity of the unordered pair {i, j}; NaN = pair absent (pica2.py:85-87 keying)
 __device__ inline double sim_get(const SimView &S, uint32_t i, uint32_t j) {
     if (i > j) { const uint32_t t = i; i = j; j = t; }
-    double v;
-    if (S.dense) {
-        v = S.dense[(uint64_t)i * S.ld + j];
-    } else {
-        const int64_t I = gram_at(S, i, j);
-        const int64_t ai = S.diag ? S.diag[i] : gram_at(S, i, i);
-        const int64_t aj = S.diag ? S.diag[j] : gram_at(S, j, j);
-        if (S.kind == IMPOP_IDENTITY_MATCH) {
-            const int64_t H = ai + aj - 2 * I;
-            if ((uint64_t)H < S.tbl_n) return S.tbl[H];  // memoised (already rounded)
-            v = S.W ? (double)((int64_t)S.W - H) / (double)S.W : 1.0;
-        } else {
-            const int64_t d = ai + aj;
-            v = d ? (double)(2 * I) / (double)d : 1.0;
-        }
-    }
+    if (!S.dense)
+        return sim_from_gram(S, gram_at(S, i, j), S.diag ? S.diag[i] : gram_at(S, i, i), S.diag ? S.diag[j] : gram_at(S, j, j));
+    double v = S.dense[(uint64_t)i * S.ld + j];
     if (S.round_digits >= 0 && v == v) v = py_round(v, S.round_digits);
     return v;
 }

@@ -343,17 +343,24 @@ IMPOP_API int impop_matrix_download(impop_ctx *ctx, const impop_matrix *m, uint6
 // scanned with windows in the original coordinates: same records, ~W/S times fewer bytes.
 namespace impop {
 
+// grid-stride over blocks: a workgroup per 4 blocks cost more in launches than in bytes (37 ms for 14.6 GB)
 __global__ __launch_bounds__(256) void variable_mask_kernel(const uint32_t *__restrict__ sb, uint32_t wps, uint32_t G,
                                                             uint32_t r, uint64_t n_block, uint64_t n_site, uint32_t n_hap,
                                                             uint64_t *__restrict__ mask, uint32_t *__restrict__ cnt) {
     const uint32_t lane = threadIdx.x & 63;
-    const uint64_t b = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (b >= n_block) return;
-    uint32_t c = 0;
-    for (uint32_t k = 0; k < wps; ++k) c += __popc(sb[sb_index(wps, G, r, b, lane, k)]);
-    const bool var = (b * 64 + lane < n_site) && c > 0 && c < n_hap;
-    const uint64_t m = __ballot(var);
-    if (lane == 0) { mask[b] = m; cnt[b] = (uint32_t)__popcll(m); }
+    const uint64_t stride = (uint64_t)gridDim.x * 4;
+    for (uint64_t b = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6); b < n_block; b += stride) {
+        const uint32_t *site = sb + b * 64ull * wps;
+        uint32_t c = 0;
+        for (uint32_t g = 0; g + 1 < G; ++g) {  // whole 16-byte granules: one coalesced 1 KiB wave load each
+            const uint4 v = *reinterpret_cast<const uint4 *>(site + (uint64_t)g * 256 + lane * 4);
+            c += __popc(v.x) + __popc(v.y) + __popc(v.z) + __popc(v.w);
+        }
+        for (uint32_t j = 0; j < r; ++j) c += __popc(site[(uint64_t)(G - 1) * 256 + lane * r + j]);
+        const bool var = (b * 64 + lane < n_site) && c > 0 && c < n_hap;
+        const uint64_t m = __ballot(var);
+        if (lane == 0) { mask[b] = m; cnt[b] = (uint32_t)__popcll(m); }
+    }
 }
 
 constexpr uint32_t SCAN_CHUNK = 1024;  // blocks per workgroup in the two-level exclusive scan
@@ -400,14 +407,16 @@ __global__ __launch_bounds__(256) void gather_variable_kernel(const uint32_t *__
                                                               const uint64_t *__restrict__ base, uint32_t *__restrict__ out,
                                                               uint64_t *__restrict__ pos) {
     const uint32_t lane = threadIdx.x & 63;
-    const uint64_t b = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (b >= n_block) return;
-    const uint64_t m = mask[b];
-    if (!((m >> lane) & 1ull)) return;
-    const uint64_t dest = base[b] + (uint64_t)__popcll(m & ((1ull << lane) - 1ull));
-    for (uint32_t k = 0; k < wps; ++k)
-        out[sb_index(wps, G, r, dest >> 6, (uint32_t)(dest & 63), k)] = sb[sb_index(wps, G, r, b, lane, k)];
-    pos[dest] = b * 64 + lane;
+    const uint64_t stride = (uint64_t)gridDim.x * 4;
+    for (uint64_t b = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6); b < n_block; b += stride) {
+        const uint64_t m = mask[b];
+        if (!m) continue;  // wave-uniform: most blocks of a real matrix hold a few variable sites, many none
+        if (!((m >> lane) & 1ull)) continue;
+        const uint64_t dest = base[b] + (uint64_t)__popcll(m & ((1ull << lane) - 1ull));
+        for (uint32_t k = 0; k < wps; ++k)
+            out[sb_index(wps, G, r, dest >> 6, (uint32_t)(dest & 63), k)] = sb[sb_index(wps, G, r, b, lane, k)];
+        pos[dest] = b * 64 + lane;
+    }
 }
 
 void map_windows(const impop_matrix *m, const impop_window *windows, uint64_t n, std::vector<impop_window> &mapped) {
@@ -440,8 +449,9 @@ IMPOP_API int impop_matrix_compact(impop_ctx *ctx, const impop_matrix *in, impop
     uint32_t *d_cnt = (uint32_t *)((char *)d + o_cnt);
     uint64_t n_kept = 0;
     if (nb) {
-        hipLaunchKernelGGL(variable_mask_kernel, dim3((uint32_t)((nb + 3) / 4)), dim3(256), 0, ctx->stream, in->d_sb, g.wps, g.G, g.r,
-                           nb, g.n_site, g.n_hap, d_mask, d_cnt);
+        const uint32_t wide_grid = (uint32_t)std::min<uint64_t>((nb + 3) / 4, 32ull * (uint64_t)(ctx->n_cu > 0 ? ctx->n_cu : 256));
+        hipLaunchKernelGGL(variable_mask_kernel, dim3(wide_grid), dim3(256), 0, ctx->stream, in->d_sb, g.wps, g.G, g.r, nb, g.n_site,
+                           g.n_hap, d_mask, d_cnt);
         hipLaunchKernelGGL(chunk_sum_kernel, dim3((uint32_t)n_chunks), dim3(256), 0, ctx->stream, d_cnt, nb, d_chunk);
         hipLaunchKernelGGL(chunk_scan_kernel, dim3(1), dim3(64), 0, ctx->stream, d_chunk, n_chunks, d_total);
         hipLaunchKernelGGL(block_base_kernel, dim3((uint32_t)n_chunks), dim3(64), 0, ctx->stream, d_cnt, nb, d_chunk, d_base);
@@ -468,8 +478,9 @@ IMPOP_API int impop_matrix_compact(impop_ctx *ctx, const impop_matrix *in, impop
             return fail(hip_fail(err, what, __FILE__, __LINE__));
         };
         if ((e = hipMemsetAsync(m->d_sb, 0, m->sb_bytes, ctx->stream)) != hipSuccess) return fail2(e, "hipMemsetAsync");
-        hipLaunchKernelGGL(gather_variable_kernel, dim3((uint32_t)((nb + 3) / 4)), dim3(256), 0, ctx->stream, in->d_sb, g.wps, g.G,
-                           g.r, nb, d_mask, d_base, m->d_sb, d_pos);
+        const uint32_t wide_grid = (uint32_t)std::min<uint64_t>((nb + 3) / 4, 32ull * (uint64_t)(ctx->n_cu > 0 ? ctx->n_cu : 256));
+        hipLaunchKernelGGL(gather_variable_kernel, dim3(wide_grid), dim3(256), 0, ctx->stream, in->d_sb, g.wps, g.G, g.r, nb, d_mask,
+                           d_base, m->d_sb, d_pos);
         if ((e = hipGetLastError()) != hipSuccess) return fail2(e, "gather_variable_kernel");
         if ((e = hipMemcpyAsync(m->pos.data(), d_pos, n_kept * 8, hipMemcpyDeviceToHost, ctx->stream)) != hipSuccess)
             return fail2(e, "hipMemcpyAsync(positions)");

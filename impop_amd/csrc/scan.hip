@@ -216,7 +216,10 @@ __global__ __launch_bounds__(256, IMPOP_SCAN_MIN_WAVES) void scan_tiles_kernel(c
 constexpr int SB_MAX = 8;   // blocks per wave per tile => tile_blocks <= 32 for this kernel
 constexpr int SB_CH = 16;   // dwords per chunk
 
-__global__ __launch_bounds__(256, 4) void scan_tiles_generic_kernel(const uint32_t *__restrict__ sb,
+#ifndef IMPOP_SCAN_GENERIC_WAVES
+#define IMPOP_SCAN_GENERIC_WAVES 4
+#endif
+__global__ __launch_bounds__(256, IMPOP_SCAN_GENERIC_WAVES) void scan_tiles_generic_kernel(const uint32_t *__restrict__ sb,
                                                                     const ScanTile *__restrict__ tiles,
                                                                     const uint32_t *__restrict__ masks, uint32_t wps,
                                                                     uint32_t G, uint32_t r, const PopSizes ps,

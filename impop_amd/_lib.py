@@ -111,6 +111,7 @@ SIGNATURES = {
                                       C.POINTER(PairwiseParams), C.POINTER(PairwiseStats)]),
     "impop_pi_from_identity": (C.c_int, [_vp, _f64p, C.c_uint32, C.c_double, C.c_int, C.c_uint64, _f64p, _f64p, _u32p, _u32p]),
     "impop_fst_from_identity": (C.c_int, [_vp, _f64p, C.c_uint32, _u8p, _u8p, C.c_uint64, C.c_int, _f64p, _u64p]),
+    "impop_matrix_set_site_weights": (C.c_int, [_vp, _vp, _u32p]),
     "impop_matrix_compact": (C.c_int, [_vp, _vp, C.POINTER(_vp)]),
     "impop_matrix_positions": (C.c_int, [_vp, C.c_uint64, C.c_uint64, _u64p, _u64p]),
     "impop_ehh": (C.c_int, [_vp, _vp, C.c_uint64, C.c_uint64, _u64p, C.c_int, _f64p, _u32p]),

@@ -38,6 +38,14 @@ int hip_fail(hipError_t e, const char *what, const char *file, int line);
         }                                                                                                      \
     } while (0)
 
+#define NOT_WEIGHTED(m, fn)                                                                  \
+    do {                                                                                     \
+        if ((m)->d_wt) {                                                                     \
+            impop::set_error("%s: not available on a matrix with site weights", fn);         \
+            return IMPOP_E_UNSUPPORTED;                                                      \
+        }                                                                                    \
+    } while (0)
+
 // ---- SB64: site-blocked, wave-interleaved layout --------------------------------
 // The site axis is cut into blocks of 64 sites (one wavefront).  A site holds
 // wps = ceil(n_hap/32) dwords (dword k = haplotypes 32k..32k+31).  Inside a block the
@@ -97,6 +105,7 @@ struct impop_matrix {
     uint64_t rb_bytes = 0;
     // compacted matrix (impop_matrix_compact): only the sites variable among all haplotypes were kept;
     // pos[k] = original index of kept site k (host copy for window mapping), n_site_orig = original length
+    uint32_t *d_wt = nullptr;  // optional per-site weights (impop_matrix_set_site_weights), plain site order
     bool compact = false;
     uint64_t n_site_orig = 0;
     std::vector<uint64_t> pos;

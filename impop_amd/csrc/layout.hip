@@ -434,6 +434,7 @@ IMPOP_API int impop_matrix_compact(impop_ctx *ctx, const impop_matrix *in, impop
     REQUIRE(ctx && in && out, "impop_matrix_compact: NULL argument");
     *out = nullptr;
     REQUIRE(!in->compact, "impop_matrix_compact: matrix is already compacted");
+    NOT_WEIGHTED(in, "impop_matrix_compact");
     HIP_TRY(hipSetDevice(ctx->device));
     const SbGeom &g = in->g;
     const uint64_t nb = g.n_block, n_chunks = (nb + SCAN_CHUNK - 1) / SCAN_CHUNK;
@@ -491,6 +492,21 @@ IMPOP_API int impop_matrix_compact(impop_ctx *ctx, const impop_matrix *in, impop
     return IMPOP_OK;
 }
 
+IMPOP_API int impop_matrix_set_site_weights(impop_ctx *ctx, impop_matrix *m, const uint32_t *weights_host) {
+    REQUIRE(ctx && m, "impop_matrix_set_site_weights: NULL argument");
+    NOT_COMPACT(m, "impop_matrix_set_site_weights");
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));  // launches in flight may still read the old weights
+    if (m->d_wt) {
+        HIP_TRY(hipFree(m->d_wt));
+        m->d_wt = nullptr;
+    }
+    if (!weights_host || m->g.n_site == 0) return IMPOP_OK;
+    HIP_TRY(hipMalloc((void **)&m->d_wt, m->g.n_site * 4ull));
+    HIP_TRY(hipMemcpy(m->d_wt, weights_host, m->g.n_site * 4ull, hipMemcpyHostToDevice));
+    return IMPOP_OK;
+}
+
 IMPOP_API int impop_matrix_positions(const impop_matrix *m, uint64_t first, uint64_t count, uint64_t *out, uint64_t *n_site_orig) {
     REQUIRE(m, "impop_matrix_positions: matrix is NULL");
     REQUIRE(m->compact, "impop_matrix_positions: not a compacted matrix");
@@ -520,6 +536,7 @@ IMPOP_API int impop_matrix_free(impop_ctx *ctx, impop_matrix *m) {
     }
     if (m->d_sb) hipFree(m->d_sb);
     if (m->d_rb) hipFree(m->d_rb);
+    if (m->d_wt) hipFree(m->d_wt);
     delete m;
     return IMPOP_OK;
 }

@@ -631,6 +631,7 @@ using namespace impop;
 static int check_pairwise_args(impop_ctx *ctx, const impop_matrix *m, uint64_t s0, uint64_t s1, const char *fn) {
     REQUIRE(ctx && m, "%s: NULL argument", fn);
     NOT_COMPACT(m, fn);
+    NOT_WEIGHTED(m, fn);
     REQUIRE(m->d_rb, "%s: matrix was created without IMPOP_KEEP_HAP_MAJOR", fn);
     REQUIRE(s0 <= s1 && s1 <= m->g.n_site, "%s: bad site range [%llu,%llu)", fn, (unsigned long long)s0,
             (unsigned long long)s1);
@@ -700,6 +701,7 @@ IMPOP_API int impop_pairwise_scan(impop_ctx *ctx, const impop_matrix *m, const i
                                   const impop_pairwise_params *params, impop_pairwise_stats *out_host) {
     REQUIRE(ctx && m && params, "impop_pairwise_scan: NULL argument");
     NOT_COMPACT(m, "impop_pairwise_scan");
+    NOT_WEIGHTED(m, "impop_pairwise_scan");
     REQUIRE(params->struct_size == sizeof(impop_pairwise_params), "impop_pairwise_params.struct_size mismatch");
     REQUIRE(m->d_rb, "impop_pairwise_scan: matrix was created without IMPOP_KEEP_HAP_MAJOR");
     REQUIRE(params->identity_kind == IMPOP_IDENTITY_MATCH || params->identity_kind == IMPOP_IDENTITY_DICE,

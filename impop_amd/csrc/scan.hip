@@ -21,9 +21,10 @@ namespace impop {
 struct ScanTile {
     uint64_t site_begin, site_end;
 };
-struct TilePartial {  // 48 B
+struct TilePartial {  // 56 B
     uint32_t s_all, s_p, s_a, s_b;
     uint64_t sum_p, sum_a, sum_b, sum_ab;
+    uint64_t sum_w;  // weighted scans only: sum of the site weights of the tile
 };
 struct WinDesc {
     uint64_t t0, t1;  // tile range
@@ -295,28 +296,96 @@ __global__ __launch_bounds__(256, IMPOP_SCAN_GENERIC_WAVES) void scan_tiles_gene
     tile_reduce_store(acc, out);
 }
 
+// Weighted sites (impop_matrix_set_site_weights): column s stands for w_s base pairs (a graph node of
+// that length), so every sum_s c (n - c) becomes sum_s w_s c (n - c) and the window's W is sum_s w_s —
+// exactly what scanning the bp-expanded matrix gives — while the segregating-site counts stay counts of
+// COLUMNS (variable nodes, what a VCF of the window lists).  Node-level matrices are small; this kernel
+// takes any wps with masks read from memory and is not the tuned hot path.
+__global__ __launch_bounds__(256) void scan_tiles_weighted_kernel(const uint32_t *__restrict__ sb, const ScanTile *__restrict__ tiles,
+                                                                  const uint32_t *__restrict__ masks, uint32_t wps, uint32_t G,
+                                                                  uint32_t r, const PopSizes ps, const uint32_t *__restrict__ weights,
+                                                                  TilePartial *__restrict__ out) {
+    __shared__ uint64_t red[4][9];
+    const ScanTile t = tiles[blockIdx.x];
+    const uint64_t b0 = t.site_begin >> 6, b1 = (t.site_end + 63) >> 6;
+    const uint32_t lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t *mp = masks, *ma = masks + wps, *mb = masks + 2 * wps;
+    uint64_t acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};  // s_all, s_p, s_a, s_b, q_p, q_a, q_b, q_ab, sum_w
+    for (uint64_t b = b0 + wave; b < b1; b += 4) {
+        const uint32_t *blk = sb + b * 64ull * wps;
+        uint32_t c = 0, cP = 0, cA = 0, cB = 0;
+        for (uint32_t g = 0; g + 1 < G; ++g) {
+            const u32v4 v = stream_load(reinterpret_cast<const u32v4 *>(blk + (uint64_t)g * 256 + lane * 4));
+            const uint32_t w4[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const uint32_t k = 4 * g + e;
+                c += __popc(w4[e]); cP += __popc(w4[e] & mp[k]); cA += __popc(w4[e] & ma[k]); cB += __popc(w4[e] & mb[k]);
+            }
+        }
+        for (uint32_t e = 0; e < r; ++e) {
+            const uint32_t v = stream_load(blk + (uint64_t)(G - 1) * 256 + lane * r + e), k = 4 * (G - 1) + e;
+            c += __popc(v); cP += __popc(v & mp[k]); cA += __popc(v & ma[k]); cB += __popc(v & mb[k]);
+        }
+        const uint64_t s = b * 64 + lane;
+        if (s >= t.site_begin && s < t.site_end) {
+            const uint64_t wt = weights[s];
+            acc[0] += (c - 1u) < (ps.n - 1u); acc[1] += (cP - 1u) < (ps.nP - 1u);
+            acc[2] += (cA - 1u) < (ps.nA - 1u); acc[3] += (cB - 1u) < (ps.nB - 1u);
+            acc[4] += wt * ((uint64_t)cP * (ps.nP - cP));
+            acc[5] += wt * ((uint64_t)cA * (ps.nA - cA));
+            acc[6] += wt * ((uint64_t)cB * (ps.nB - cB));
+            acc[7] += wt * ((uint64_t)cA * (ps.nB - cB) + (uint64_t)cB * (ps.nA - cA));
+            acc[8] += wt;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        const uint64_t v = wave_sum_u64(acc[i]);
+        if (lane == 0) red[wave][i] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 9) {
+        const uint64_t v = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+        TilePartial *o = out + blockIdx.x;
+        switch (threadIdx.x) {
+            case 0: o->s_all = (uint32_t)v; break;
+            case 1: o->s_p = (uint32_t)v; break;
+            case 2: o->s_a = (uint32_t)v; break;
+            case 3: o->s_b = (uint32_t)v; break;
+            case 4: o->sum_p = v; break;
+            case 5: o->sum_a = v; break;
+            case 6: o->sum_b = v; break;
+            case 7: o->sum_ab = v; break;
+            default: o->sum_w = v; break;
+        }
+    }
+}
+
 // One thread per window: integer totals, then the fp64 epilogue.  Same operation order as
 // oracle_window_sitecount (oracle/impop_oracle.c) which restates pica2.py:154,164,
 // h-fst.py:203-240 and tj_d.py:53-65 on the exact pair sums.
 __global__ void scan_finalize_kernel(const TilePartial *__restrict__ parts, const WinDesc *__restrict__ wins,
                                      uint64_t n_windows, PopSizes ps, const double *__restrict__ taj, int d_pi_mode,
-                                     int s_scope, impop_window_stats *__restrict__ out) {
+                                     int s_scope, int weighted, impop_window_stats *__restrict__ out) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_windows) return;
     const WinDesc w = wins[i];
     uint32_t s_all = 0, s_p = 0, s_a = 0, s_b = 0;
-    uint64_t sum_p = 0, sum_a = 0, sum_b = 0, sum_ab = 0;
+    uint64_t sum_p = 0, sum_a = 0, sum_b = 0, sum_ab = 0, sum_w = 0;
     for (uint64_t t = w.t0; t < w.t1; ++t) {
         const TilePartial p = parts[t];
         s_all += p.s_all; s_p += p.s_p; s_a += p.s_a; s_b += p.s_b;
         sum_p += p.sum_p; sum_a += p.sum_a; sum_b += p.sum_b; sum_ab += p.sum_ab;
+        if (weighted) sum_w += p.sum_w;
     }
+    const uint64_t n_sites = weighted ? sum_w : w.n_sites;  // weighted: W = sum of the window's site weights
     impop_window_stats r;
-    r.n_sites = (uint32_t)w.n_sites;
+    r.n_sites = (uint32_t)n_sites;
     r.s_all = s_all; r.s_p = s_p; r.s_a = s_a; r.s_b = s_b; r.flags = 0;
     r.sum_p = sum_p; r.sum_a = sum_a; r.sum_b = sum_b; r.sum_ab = sum_ab;
     const double nan = __builtin_nan("");
-    const double W = (double)w.n_sites;
+    const double W = (double)n_sites;
     const double seq_len = (double)w.seq_len;
     const double nP = (double)ps.nP, nA = (double)ps.nA, nB = (double)ps.nB;
     const double pairsP = nP * (double)(ps.nP - 1) / 2.0;
@@ -739,7 +808,13 @@ IMPOP_API int impop_scan_plan_launch(impop_scan_plan *p, void *d_out) {
         p->events_used++;
         HIP_TRY(hipEventRecord(ev0, st));
     }
-    if (p->n_tiles) {
+    const bool weighted = p->m->d_wt != nullptr;
+    if (p->n_tiles && weighted) {
+        hipLaunchKernelGGL(scan_tiles_weighted_kernel, dim3((uint32_t)p->n_tiles), dim3(256), 0, st, p->m->d_sb, p->d_tiles,
+                           p->d_masks, p->m->g.wps, p->m->g.G, p->m->g.r, p->ps, p->m->d_wt, p->d_parts);
+        HIP_TRY(hipGetLastError());
+        if (ev1) HIP_TRY(hipEventRecord(ev1, st));
+    } else if (p->n_tiles) {
         switch (p->m->g.wps) {
 #define CASE(W) case W: launch_scan_fixed<W>(p, st); break;
             CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8)
@@ -755,7 +830,7 @@ IMPOP_API int impop_scan_plan_launch(impop_scan_plan *p, void *d_out) {
     if (p->n_windows) {
         impop_window_stats *dst = d_out ? (impop_window_stats *)d_out : p->d_out;
         hipLaunchKernelGGL(scan_finalize_kernel, dim3((uint32_t)((p->n_windows + 127) / 128)), dim3(128), 0, st, p->d_parts,
-                           p->d_wins, p->n_windows, p->ps, ctx->d_taj, p->d_pi_mode, p->s_scope, dst);
+                           p->d_wins, p->n_windows, p->ps, ctx->d_taj, p->d_pi_mode, p->s_scope, weighted ? 1 : 0, dst);
         HIP_TRY(hipGetLastError());
     }
     return IMPOP_OK;
@@ -866,6 +941,7 @@ static void launch_multi(hipStream_t st, const impop_matrix *m, uint64_t n_tiles
 IMPOP_API int impop_scan_multi(impop_ctx *ctx, const impop_matrix *m, const impop_window *windows, uint64_t n_windows,
                                const uint64_t *masks, uint32_t n_pop, impop_pair_stats *out_host) {
     REQUIRE(ctx && m, "impop_scan_multi: NULL argument");
+    NOT_WEIGHTED(m, "impop_scan_multi");
     REQUIRE(n_pop >= 2 && n_pop <= 8, "impop_scan_multi: n_pop must be 2..8");
     REQUIRE(masks, "impop_scan_multi: masks is NULL");
     REQUIRE(m->g.n_hap <= 65535, "impop_scan_multi: n_hap > 65535 not supported");

@@ -270,6 +270,17 @@ class BitMatrix:
         except Exception:
             pass
 
+    def set_site_weights(self, weights) -> None:
+        """Per-site weights (bp per column; None removes them): scans return the records of the bp-expanded
+        matrix while the segregating-site counts keep counting columns (impop_matrix_set_site_weights)."""
+        if weights is None:
+            check(self.ctx._lib.impop_matrix_set_site_weights(self.ctx.handle, self.handle, None))
+            return
+        w = np.ascontiguousarray(weights, dtype=np.uint32)
+        if w.shape != (self.n_site,):
+            raise ValueError("weights must have one entry per site")
+        check(self.ctx._lib.impop_matrix_set_site_weights(self.ctx.handle, self.handle, w.ctypes.data_as(C.POINTER(C.c_uint32))))
+
     def compact(self) -> "BitMatrix":
         """A new matrix holding only the sites that are variable among all haplotypes.  Scans of it take
         windows in THIS matrix's site coordinates and return the same records (impop_matrix_compact)."""

@@ -116,6 +116,10 @@ def from_gfa(path: str, ref_prefix: Optional[str] = None, expand_bp: bool = True
             inner = np.concatenate([np.arange(r) if o else np.zeros(r, np.int64) for r, o in zip(reps, on_ref)]) if len(segs) else np.zeros(0, np.int64)
             node_pos = np.maximum.accumulate(pos + inner)
     mf = from_dense(mat, names)
+    if not expand_bp:
+        # one column per node, weighted by its length: BitMatrix.set_site_weights gives the records of the
+        # expanded matrix without repeating columns (zero-length segments weigh nothing)
+        mf.site_weight = np.maximum(lens, 0).astype(np.uint32)
     if node_pos is not None:
         mf.site_pos = node_pos
         mf.contig = ref_prefix or ""

@@ -24,6 +24,7 @@ class MatrixFile:
     n_site: int
     names: List[str]
     site_pos: Optional[np.ndarray] = None
+    site_weight: Optional[np.ndarray] = None  # bp per column (node-level matrices); None = 1 each
     origin: int = 0
     contig: str = ""
 
@@ -47,6 +48,8 @@ def save_matrix(path: str, m: MatrixFile) -> None:
          "names": np.array(m.names, dtype=str), "origin": np.int64(m.origin), "contig": np.array(m.contig)}
     if m.site_pos is not None:
         d["site_pos"] = np.ascontiguousarray(m.site_pos, dtype=np.int64)
+    if m.site_weight is not None:
+        d["site_weight"] = np.ascontiguousarray(m.site_weight, dtype=np.uint32)
     np.savez_compressed(path, **d)
 
 
@@ -54,6 +57,7 @@ def load_matrix(path: str) -> MatrixFile:
     with np.load(path, allow_pickle=False) as z:
         return MatrixFile(bits=z["bits"], n_site=int(z["n_site"]), names=[str(x) for x in z["names"]],
                           site_pos=z["site_pos"] if "site_pos" in z.files else None,
+                          site_weight=z["site_weight"] if "site_weight" in z.files else None,
                           origin=int(z["origin"]) if "origin" in z.files else 0,
                           contig=str(z["contig"]) if "contig" in z.files else "")
 

@@ -93,6 +93,14 @@ int impop_matrix_synthetic(impop_ctx *ctx, uint32_t n_hap, uint64_t n_site, cons
  * (bit 0 of word 0 of each row = site_begin). */
 int impop_matrix_download(impop_ctx *ctx, const impop_matrix *m, uint64_t site_begin, uint64_t site_end,
                           uint64_t *bits_hap_major_out, uint64_t row_stride_words);
+/* Optional per-site weights (NULL removes them): column s stands for weights[s] base pairs, e.g. one
+ * column per graph node with the node's length, instead of repeating the column per bp.  impop_scan /
+ * impop_scan_plan_* then return sum_s w_s c(n-c) sums and n_sites = sum_s w_s over the window — the
+ * records of the bp-expanded matrix — while s_all / s_p / s_a / s_b keep counting COLUMNS (variable nodes,
+ * what a VCF of the window lists, run_tajd.sh:148).  Not combinable with impop_matrix_compact,
+ * impop_scan_multi or the all-pairs path (IMPOP_E_UNSUPPORTED). */
+int impop_matrix_set_site_weights(impop_ctx *ctx, impop_matrix *m, const uint32_t *weights_host);
+
 /* Keep only the sites that are variable among ALL haplotypes (0 < c_s < n), with their original
  * positions.  Monomorphic sites add 0 to every sum_s c(n-c) of every subset and are never segregating
  * (what `povu gfa2vcf | wc -l` counts, run_tajd.sh:148), so impop_scan / impop_scan_plan_* /

@@ -114,10 +114,15 @@ def main():
         loc = loc.copy()
         loc["site_begin"] += np.uint64(shift)
         loc["site_end"] += np.uint64(shift)
-        bm = ctx.upload(slab, max(min(mf.n_site, 64 * w1) - 64 * w0, 0), keep_hap_major=need_pairwise)
+        n_slab = max(min(mf.n_site, 64 * w1) - 64 * w0, 0)
+        bm = ctx.upload(slab, n_slab, keep_hap_major=need_pairwise)
+        if mf.site_weight is not None:
+            bm.set_site_weights(mf.site_weight[64 * w0: 64 * w0 + n_slab])
         wins = [(int(w["site_begin"]), int(w["site_end"]), int(w["seq_len"])) for w in loc]
     else:
         bm = ctx.upload(mf.bits, mf.n_site, keep_hap_major=need_pairwise)
+        if mf.site_weight is not None:
+            bm.set_site_weights(mf.site_weight)
     if args.compact:
         if need_pairwise:
             print("Error: --compact cannot be combined with thresholded / rounded pica2 (all-pairs path)", file=sys.stderr)

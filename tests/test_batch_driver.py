@@ -159,3 +159,45 @@ def test_batch_driver_two_ranks_equal_one(tmp_path):
                            capture_output=True, text=True)
     assert two_p.returncode == 0, two_p.stderr[-2000:]
     assert open(tmp_path / "two_p.tsv").read() == one_p.stdout
+
+
+def test_batch_driver_node_level_matrix_with_weights(tmp_path):
+    """A GFA extracted with one weighted column per node (--no-expand-bp) gives the same pica2 / h-fst
+    tables as the bp-expanded extraction when the BED rows fall on node boundaries."""
+    rng = np.random.default_rng(3)
+    n_node, n_hap = 60, 10
+    lens = rng.integers(1, 30, size=n_node)
+    seqs = ["".join(rng.choice(list("ACGT"), size=int(L))) for L in lens]
+    lines = ["H\tVN:Z:1.0"] + [f"S\t{i + 1}\t{seqs[i]}" for i in range(n_node)]
+    ref_nodes = list(range(0, n_node, 2)) + []  # the reference takes the even nodes (odd ones are alternative alleles)
+    ref_nodes = sorted(ref_nodes)
+    ref_len = int(sum(lens[i] for i in ref_nodes))
+    lines.append("P\tCHM13#0#chr7:0-%d\t%s\t*" % (ref_len, ",".join(f"{i + 1}+" for i in ref_nodes)))
+    for h in range(n_hap):
+        steps = []
+        for i in range(0, n_node, 2):
+            steps.append(i if rng.random() < 0.7 else min(i + 1, n_node - 1))
+        lines.append("P\tS%03d#%d#ctg:0-1\t%s\t*" % (h // 2, h % 2 + 1, ",".join(f"{i + 1}+" for i in steps)))
+    (tmp_path / "g.gfa").write_text("\n".join(lines) + "\n")
+    ex = os.path.join(ROOT, "scripts", "impop_extract.py")
+    for out, extra in (("exp.npz", []), ("node.npz", ["--no-expand-bp"])):
+        r = subprocess.run([sys.executable, ex, "--gfa", str(tmp_path / "g.gfa"), "--ref-prefix", "CHM13#0#", "-o", str(tmp_path / out)] + extra,
+                           capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+    # BED rows cut at reference-node starts (coordinates where a new reference node begins)
+    starts = np.concatenate(([0], np.cumsum([lens[i] for i in ref_nodes])))
+    bed = [(int(starts[2]), int(starts[12])), (int(starts[12]), int(starts[25])), (0, int(starts[-1]))]
+    (tmp_path / "w.bed").write_text("".join(f"chr7\t{a}\t{b}\n" for a, b in bed))
+    (tmp_path / "A.txt").write_text("S000\nS001\n")
+    (tmp_path / "B.txt").write_text("S002\nS003\nS004\n")
+    outs = {}
+    for name in ("exp.npz", "node.npz"):
+        for fmt in ("pica2", "hfst"):
+            r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "impop_scan.py"), "--matrix", str(tmp_path / name), "--bed",
+                                str(tmp_path / "w.bed"), "--format", fmt, "-A", str(tmp_path / "A.txt"), "-B", str(tmp_path / "B.txt")],
+                               capture_output=True, text=True)
+            assert r.returncode == 0, r.stderr
+            outs[(name, fmt)] = r.stdout
+    assert outs[("exp.npz", "pica2")] == outs[("node.npz", "pica2")]
+    assert outs[("exp.npz", "hfst")] == outs[("node.npz", "hfst")]
+    assert outs[("exp.npz", "hfst")].count("\n") == 4

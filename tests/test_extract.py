@@ -24,6 +24,7 @@ def test_from_gfa(tmp_path):
     m = impop_amd.unpack_hap_major(mf.bits, mf.n_site)
     assert m.tolist() == [[1, 1, 0, 1, 1], [1, 0, 1, 1, 1], [0, 1, 0, 1, 0], [1, 1, 0, 1, 0]]
     assert mf.site_pos.tolist() == [1000, 1004, 1004, 1005, 1010]
+    assert mf.site_weight.tolist() == [4, 1, 1, 5, 3]  # node lengths: the weights of the node-level columns
     e = extract.from_gfa(str(p), ref_prefix="CHM13#0#", expand_bp=True)
     assert e.n_site == 4 + 1 + 1 + 5 + 3
     me = impop_amd.unpack_hap_major(e.bits, e.n_site)
@@ -34,6 +35,9 @@ def test_from_gfa(tmp_path):
     matrixio.save_matrix(str(tmp_path / "m.npz"), e)
     z = matrixio.load_matrix(str(tmp_path / "m.npz"))
     assert z.names == e.names and z.n_site == e.n_site and (z.bits == e.bits).all() and (z.site_pos == e.site_pos).all()
+    assert e.site_weight is None and z.site_weight is None
+    matrixio.save_matrix(str(tmp_path / "n.npz"), mf)
+    assert matrixio.load_matrix(str(tmp_path / "n.npz")).site_weight.tolist() == [4, 1, 1, 5, 3]
 
 
 def test_from_paths_table(tmp_path):

@@ -807,3 +807,56 @@ def test_pairwise_scan_overlapping_windows_share_segments(ctx, oracle):
     pi, ps, _, G = oracle.pica2(sim, 0.995, L, 4)
     assert rel_close(float(r["pi"]), pi, REL, 1e-300) and int(r["n_groups"]) == G
     bm.free()
+
+
+def test_weighted_sites_equal_bp_expanded_matrix(ctx, oracle):
+    """impop_matrix_set_site_weights: one column per graph node with its length as weight must give the
+    records of the bp-expanded matrix (the same integer sums, n_sites, pi, Fst ...), except that the
+    segregating-site counts count variable NODES; Tajima's D follows from that S (checked via the oracle)."""
+    from impop_amd import ImpopError
+    rng = np.random.default_rng(17)
+    for n, K in ((37, 900), (600, 300)):  # fixed-WPS and any-n matrices
+        nodes = (rng.random((n, K)) < rng.random(K) * 0.6).astype(np.uint8)
+        nodes[:, rng.random(K) < 0.3] = 1                       # nodes every haplotype passes through
+        length = rng.integers(1, 40, size=K).astype(np.uint32)
+        cum = np.concatenate(([0], np.cumsum(length))).astype(np.int64)
+        expanded = np.repeat(nodes, length, axis=1)
+        bn = ctx.upload_dense(nodes, keep_hap_major=False)
+        be = ctx.upload_dense(expanded, keep_hap_major=False)
+        bn.set_site_weights(length)
+        inA = (rng.random(n) < 0.4).astype(np.uint8); inB = (rng.random(n) < 0.4).astype(np.uint8)
+        inP = (rng.random(n) < 0.8).astype(np.uint8)
+        wn = [(0, K, 0), (3, 500 if K > 500 else 200, 12345), (K // 2, K // 2 + 1, 7), (10, 10, 0), (K - 64, K, 99)]
+        we = [(int(cum[a]), int(cum[b]), L) for a, b, L in wn]
+        for mp in (None, inP):
+            got = bn.scan(wn, mp, inA, inB, d_pi_mode=1)
+            ref = be.scan(we, mp, inA, inB, d_pi_mode=1)
+            for k in ("n_sites", "sum_p", "sum_a", "sum_b", "sum_ab", "pi", "pi_site", "pi_a", "pi_b", "pi_xy", "dxy", "da", "fst"):
+                x, y = got[k], ref[k]
+                assert ((x == y) | ((x != x) & (y != y))).all(), (n, k, x, y)
+            c = nodes.sum(axis=0)
+            sel = nodes[(np.ones(n, bool) if mp is None else mp.astype(bool))]
+            cp = sel.sum(axis=0)
+            for (a, b, L), r in zip(wn, got):
+                assert int(r["s_all"]) == int(((c[a:b] > 0) & (c[a:b] < n)).sum())
+                assert int(r["s_p"]) == int(((cp[a:b] > 0) & (cp[a:b] < sel.shape[0])).sum())
+                ps = float(r["pi_site"])
+                if sel.shape[0] >= 2 and ps == ps:
+                    D, _ = oracle.tajimas_d(sel.shape[0], float(int(r["s_all"])), ps)
+                    d = float(r["tajima_d"])
+                    assert (d != d and D != D) or rel_close(d, D, REL, 1e-300)
+        # the oracle directly on the expanded matrix for one window
+        a, b, L = wn[1]
+        want = oracle.window_sitecount(oracle.pack_hap_major(expanded), n, int(cum[a]), int(cum[b]), oracle.pack_mask(np.ones(n, np.uint8)),
+                                       oracle.pack_mask(inA), oracle.pack_mask(inB), L, 1, 0)
+        r = bn.scan([wn[1]], None, inA, inB, d_pi_mode=1)[0]
+        for k in ("n_sites", "sum_p", "sum_a", "sum_b", "sum_ab"):
+            assert int(r[k]) == int(want[k]), k
+        for k in ("pi", "pi_site", "fst", "dxy"):
+            assert rel_close(float(r[k]), float(want[k]), REL, 1e-300), k
+        for call in (lambda: bn.compact(), lambda: bn.scan_multi(wn, [inA & ~inB, inB & ~inA])):
+            with pytest.raises(ImpopError):
+                call()
+        bn.set_site_weights(None)  # weights removed: plain node-level scan again
+        assert int(bn.scan([wn[0]])[0]["n_sites"]) == K
+        bn.free(); be.free()

@@ -109,6 +109,7 @@ struct impop_matrix {
     bool compact = false;
     uint64_t n_site_orig = 0;
     std::vector<uint64_t> pos;
+    std::vector<uint64_t> wt_prefix;  // compacted + weighted: prefix sums of the ORIGINAL weights (n_site_orig + 1)
     int device = 0;
     mutable int users = 0;      // live scan plans referencing this matrix (impop_matrix_free refuses while > 0)
 };

@@ -434,7 +434,6 @@ IMPOP_API int impop_matrix_compact(impop_ctx *ctx, const impop_matrix *in, impop
     REQUIRE(ctx && in && out, "impop_matrix_compact: NULL argument");
     *out = nullptr;
     REQUIRE(!in->compact, "impop_matrix_compact: matrix is already compacted");
-    NOT_WEIGHTED(in, "impop_matrix_compact");
     HIP_TRY(hipSetDevice(ctx->device));
     const SbGeom &g = in->g;
     const uint64_t nb = g.n_block, n_chunks = (nb + SCAN_CHUNK - 1) / SCAN_CHUNK;
@@ -487,6 +486,23 @@ IMPOP_API int impop_matrix_compact(impop_ctx *ctx, const impop_matrix *in, impop
             return fail2(e, "hipMemcpyAsync(positions)");
         if ((e = hipStreamSynchronize(ctx->stream)) != hipSuccess) return fail2(e, "hipStreamSynchronize");
         hipFree(d_pos);
+    }
+    if (in->d_wt) {
+        // weighted input: the kept columns keep their weights; a window's W is still the sum over ALL its original
+        // columns (monomorphic ones included), hence the prefix sums of the original weights stay on the host
+        std::vector<uint32_t> w(g.n_site);
+        hipError_t e = hipMemcpy(w.data(), in->d_wt, g.n_site * 4ull, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) return fail(hip_fail(e, "hipMemcpy(weights)", __FILE__, __LINE__));
+        m->wt_prefix.resize(g.n_site + 1);
+        m->wt_prefix[0] = 0;
+        for (uint64_t i = 0; i < g.n_site; ++i) m->wt_prefix[i + 1] = m->wt_prefix[i] + w[i];
+        if (n_kept) {
+            std::vector<uint32_t> kept(n_kept);
+            for (uint64_t k = 0; k < n_kept; ++k) kept[k] = w[m->pos[k]];
+            if ((e = hipMalloc((void **)&m->d_wt, n_kept * 4ull)) != hipSuccess) return fail(hip_fail(e, "hipMalloc(weights)", __FILE__, __LINE__));
+            if ((e = hipMemcpy(m->d_wt, kept.data(), n_kept * 4ull, hipMemcpyHostToDevice)) != hipSuccess)
+                return fail(hip_fail(e, "hipMemcpy(weights)", __FILE__, __LINE__));
+        }
     }
     *out = m;
     return IMPOP_OK;

@@ -747,7 +747,9 @@ IMPOP_API int impop_scan_plan_create(impop_ctx *ctx, const impop_matrix *m, cons
         std::vector<impop_window> mapped;  // compacted matrix: original coordinates -> kept-site index ranges
         map_windows(m, windows, n_windows, mapped);
         build_tiles(mapped.data(), n_windows, tile_blocks, wps, tiles, wd, p->bytes_streamed);
-        for (uint64_t i = 0; m->compact && i < n_windows; ++i) wd[i].n_sites = windows[i].site_end - windows[i].site_begin;
+        for (uint64_t i = 0; m->compact && i < n_windows; ++i)
+            wd[i].n_sites = m->wt_prefix.empty() ? windows[i].site_end - windows[i].site_begin
+                                                 : m->wt_prefix[windows[i].site_end] - m->wt_prefix[windows[i].site_begin];
     }
     p->n_tiles = tiles.size();
     auto fail = [&](int code) {
@@ -808,7 +810,10 @@ IMPOP_API int impop_scan_plan_launch(impop_scan_plan *p, void *d_out) {
         p->events_used++;
         HIP_TRY(hipEventRecord(ev0, st));
     }
-    const bool weighted = p->m->d_wt != nullptr;
+    // weights on the matrix, or a weighted matrix that was compacted (then even a window without any kept column
+    // has W = the sum of its original weights, which the plan took from the host prefix sums)
+    const bool weighted = p->m->d_wt != nullptr || !p->m->wt_prefix.empty();
+    const bool w_from_tiles = weighted && !p->m->compact;
     if (p->n_tiles && weighted) {
         hipLaunchKernelGGL(scan_tiles_weighted_kernel, dim3((uint32_t)p->n_tiles), dim3(256), 0, st, p->m->d_sb, p->d_tiles,
                            p->d_masks, p->m->g.wps, p->m->g.G, p->m->g.r, p->ps, p->m->d_wt, p->d_parts);
@@ -830,7 +835,7 @@ IMPOP_API int impop_scan_plan_launch(impop_scan_plan *p, void *d_out) {
     if (p->n_windows) {
         impop_window_stats *dst = d_out ? (impop_window_stats *)d_out : p->d_out;
         hipLaunchKernelGGL(scan_finalize_kernel, dim3((uint32_t)((p->n_windows + 127) / 128)), dim3(128), 0, st, p->d_parts,
-                           p->d_wins, p->n_windows, p->ps, ctx->d_taj, p->d_pi_mode, p->s_scope, weighted ? 1 : 0, dst);
+                           p->d_wins, p->n_windows, p->ps, ctx->d_taj, p->d_pi_mode, p->s_scope, w_from_tiles ? 1 : 0, dst);
         HIP_TRY(hipGetLastError());
     }
     return IMPOP_OK;

@@ -97,8 +97,9 @@ int impop_matrix_download(impop_ctx *ctx, const impop_matrix *m, uint64_t site_b
  * column per graph node with the node's length, instead of repeating the column per bp.  impop_scan /
  * impop_scan_plan_* then return sum_s w_s c(n-c) sums and n_sites = sum_s w_s over the window — the
  * records of the bp-expanded matrix — while s_all / s_p / s_a / s_b keep counting COLUMNS (variable nodes,
- * what a VCF of the window lists, run_tajd.sh:148).  Not combinable with impop_matrix_compact,
- * impop_scan_multi or the all-pairs path (IMPOP_E_UNSUPPORTED). */
+ * what a VCF of the window lists, run_tajd.sh:148).  impop_matrix_compact keeps the weights (a window's W stays
+ * the sum over all its original columns).  Not combinable with impop_scan_multi or the all-pairs path
+ * (IMPOP_E_UNSUPPORTED). */
 int impop_matrix_set_site_weights(impop_ctx *ctx, impop_matrix *m, const uint32_t *weights_host);
 
 /* Keep only the sites that are variable among ALL haplotypes (0 < c_s < n), with their original

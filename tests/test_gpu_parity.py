@@ -854,9 +854,15 @@ def test_weighted_sites_equal_bp_expanded_matrix(ctx, oracle):
             assert int(r[k]) == int(want[k]), k
         for k in ("pi", "pi_site", "fst", "dxy"):
             assert rel_close(float(r[k]), float(want[k]), REL, 1e-300), k
-        for call in (lambda: bn.compact(), lambda: bn.scan_multi(wn, [inA & ~inB, inB & ~inA])):
-            with pytest.raises(ImpopError):
-                call()
+        # compaction keeps the weights of the kept nodes and the windows' full weight (monomorphic nodes included)
+        cw = bn.compact()
+        assert cw.n_site < K
+        for mp in (None, inP):
+            for mode in (0, 1, 2):
+                assert cw.scan(wn, mp, inA, inB, d_pi_mode=mode).tobytes() == bn.scan(wn, mp, inA, inB, d_pi_mode=mode).tobytes()
+        cw.free()
+        with pytest.raises(ImpopError):
+            bn.scan_multi(wn, [inA & ~inB, inB & ~inA])
         bn.set_site_weights(None)  # weights removed: plain node-level scan again
         assert int(bn.scan([wn[0]])[0]["n_sites"]) == K
         bn.free(); be.free()

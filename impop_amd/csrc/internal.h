@@ -40,7 +40,7 @@ int hip_fail(hipError_t e, const char *what, const char *file, int line);
 
 #define NOT_WEIGHTED(m, fn)                                                                  \
     do {                                                                                     \
-        if ((m)->d_wt) {                                                                     \
+        if (!(m)->wt_prefix.empty()) {                                                                   \
             impop::set_error("%s: not available on a matrix with site weights", fn);         \
             return IMPOP_E_UNSUPPORTED;                                                      \
         }                                                                                    \
@@ -109,7 +109,7 @@ struct impop_matrix {
     bool compact = false;
     uint64_t n_site_orig = 0;
     std::vector<uint64_t> pos;
-    std::vector<uint64_t> wt_prefix;  // compacted + weighted: prefix sums of the ORIGINAL weights (n_site_orig + 1)
+    std::vector<uint64_t> wt_prefix;  // weighted: prefix sums of the (ORIGINAL, if compacted) site weights, n + 1 entries
     int device = 0;
     mutable int users = 0;      // live scan plans referencing this matrix (impop_matrix_free refuses while > 0)
 };

@@ -487,18 +487,14 @@ IMPOP_API int impop_matrix_compact(impop_ctx *ctx, const impop_matrix *in, impop
         if ((e = hipStreamSynchronize(ctx->stream)) != hipSuccess) return fail2(e, "hipStreamSynchronize");
         hipFree(d_pos);
     }
-    if (in->d_wt) {
+    if (!in->wt_prefix.empty()) {
         // weighted input: the kept columns keep their weights; a window's W is still the sum over ALL its original
-        // columns (monomorphic ones included), hence the prefix sums of the original weights stay on the host
-        std::vector<uint32_t> w(g.n_site);
-        hipError_t e = hipMemcpy(w.data(), in->d_wt, g.n_site * 4ull, hipMemcpyDeviceToHost);
-        if (e != hipSuccess) return fail(hip_fail(e, "hipMemcpy(weights)", __FILE__, __LINE__));
-        m->wt_prefix.resize(g.n_site + 1);
-        m->wt_prefix[0] = 0;
-        for (uint64_t i = 0; i < g.n_site; ++i) m->wt_prefix[i + 1] = m->wt_prefix[i] + w[i];
+        // columns (monomorphic ones included), so the prefix sums of the original weights travel along
+        m->wt_prefix = in->wt_prefix;
         if (n_kept) {
             std::vector<uint32_t> kept(n_kept);
-            for (uint64_t k = 0; k < n_kept; ++k) kept[k] = w[m->pos[k]];
+            for (uint64_t k = 0; k < n_kept; ++k) kept[k] = (uint32_t)(in->wt_prefix[m->pos[k] + 1] - in->wt_prefix[m->pos[k]]);
+            hipError_t e;
             if ((e = hipMalloc((void **)&m->d_wt, n_kept * 4ull)) != hipSuccess) return fail(hip_fail(e, "hipMalloc(weights)", __FILE__, __LINE__));
             if ((e = hipMemcpy(m->d_wt, kept.data(), n_kept * 4ull, hipMemcpyHostToDevice)) != hipSuccess)
                 return fail(hip_fail(e, "hipMemcpy(weights)", __FILE__, __LINE__));
@@ -511,13 +507,21 @@ IMPOP_API int impop_matrix_compact(impop_ctx *ctx, const impop_matrix *in, impop
 IMPOP_API int impop_matrix_set_site_weights(impop_ctx *ctx, impop_matrix *m, const uint32_t *weights_host) {
     REQUIRE(ctx && m, "impop_matrix_set_site_weights: NULL argument");
     NOT_COMPACT(m, "impop_matrix_set_site_weights");
+    REQUIRE(m->users == 0, "impop_matrix_set_site_weights: %d scan plan(s) were built with the current weights; destroy them first",
+            m->users);
     HIP_TRY(hipSetDevice(ctx->device));
     HIP_TRY(hipStreamSynchronize(ctx->stream));  // launches in flight may still read the old weights
     if (m->d_wt) {
         HIP_TRY(hipFree(m->d_wt));
         m->d_wt = nullptr;
     }
-    if (!weights_host || m->g.n_site == 0) return IMPOP_OK;
+    m->wt_prefix.clear();
+    if (!weights_host) return IMPOP_OK;
+    // host prefix sums: a window's W = sum of its columns' weights, looked up when a plan is built
+    m->wt_prefix.resize(m->g.n_site + 1);
+    m->wt_prefix[0] = 0;
+    for (uint64_t i = 0; i < m->g.n_site; ++i) m->wt_prefix[i + 1] = m->wt_prefix[i] + weights_host[i];
+    if (m->g.n_site == 0) return IMPOP_OK;
     HIP_TRY(hipMalloc((void **)&m->d_wt, m->g.n_site * 4ull));
     HIP_TRY(hipMemcpy(m->d_wt, weights_host, m->g.n_site * 4ull, hipMemcpyHostToDevice));
     return IMPOP_OK;

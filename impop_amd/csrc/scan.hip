@@ -21,10 +21,9 @@ namespace impop {
 struct ScanTile {
     uint64_t site_begin, site_end;
 };
-struct TilePartial {  // 56 B
+struct TilePartial {  // 48 B
     uint32_t s_all, s_p, s_a, s_b;
     uint64_t sum_p, sum_a, sum_b, sum_ab;
-    uint64_t sum_w;  // weighted scans only: sum of the site weights of the tile
 };
 struct WinDesc {
     uint64_t t0, t1;  // tile range
@@ -297,20 +296,21 @@ __global__ __launch_bounds__(256, IMPOP_SCAN_GENERIC_WAVES) void scan_tiles_gene
 }
 
 // Weighted sites (impop_matrix_set_site_weights): column s stands for w_s base pairs (a graph node of
-// that length), so every sum_s c (n - c) becomes sum_s w_s c (n - c) and the window's W is sum_s w_s —
-// exactly what scanning the bp-expanded matrix gives — while the segregating-site counts stay counts of
+// that length), so every sum_s c (n - c) becomes sum_s w_s c (n - c) and the window's W is sum_s w_s (taken
+// from host prefix sums when the plan is built) — exactly what scanning the bp-expanded matrix gives —
+// while the segregating-site counts stay counts of
 // COLUMNS (variable nodes, what a VCF of the window lists).  Node-level matrices are small; this kernel
 // takes any wps with masks read from memory and is not the tuned hot path.
 __global__ __launch_bounds__(256) void scan_tiles_weighted_kernel(const uint32_t *__restrict__ sb, const ScanTile *__restrict__ tiles,
                                                                   const uint32_t *__restrict__ masks, uint32_t wps, uint32_t G,
                                                                   uint32_t r, const PopSizes ps, const uint32_t *__restrict__ weights,
                                                                   TilePartial *__restrict__ out) {
-    __shared__ uint64_t red[4][9];
+    __shared__ uint64_t red[4][8];
     const ScanTile t = tiles[blockIdx.x];
     const uint64_t b0 = t.site_begin >> 6, b1 = (t.site_end + 63) >> 6;
     const uint32_t lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t *mp = masks, *ma = masks + wps, *mb = masks + 2 * wps;
-    uint64_t acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};  // s_all, s_p, s_a, s_b, q_p, q_a, q_b, q_ab, sum_w
+    uint64_t acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // s_all, s_p, s_a, s_b, q_p, q_a, q_b, q_ab
     for (uint64_t b = b0 + wave; b < b1; b += 4) {
         const uint32_t *blk = sb + b * 64ull * wps;
         uint32_t c = 0, cP = 0, cA = 0, cB = 0;
@@ -336,16 +336,15 @@ __global__ __launch_bounds__(256) void scan_tiles_weighted_kernel(const uint32_t
             acc[5] += wt * ((uint64_t)cA * (ps.nA - cA));
             acc[6] += wt * ((uint64_t)cB * (ps.nB - cB));
             acc[7] += wt * ((uint64_t)cA * (ps.nB - cB) + (uint64_t)cB * (ps.nA - cA));
-            acc[8] += wt;
         }
     }
 #pragma unroll
-    for (int i = 0; i < 9; ++i) {
+    for (int i = 0; i < 8; ++i) {
         const uint64_t v = wave_sum_u64(acc[i]);
         if (lane == 0) red[wave][i] = v;
     }
     __syncthreads();
-    if (threadIdx.x < 9) {
+    if (threadIdx.x < 8) {
         const uint64_t v = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
         TilePartial *o = out + blockIdx.x;
         switch (threadIdx.x) {
@@ -356,8 +355,7 @@ __global__ __launch_bounds__(256) void scan_tiles_weighted_kernel(const uint32_t
             case 4: o->sum_p = v; break;
             case 5: o->sum_a = v; break;
             case 6: o->sum_b = v; break;
-            case 7: o->sum_ab = v; break;
-            default: o->sum_w = v; break;
+            default: o->sum_ab = v; break;
         }
     }
 }
@@ -367,19 +365,18 @@ __global__ __launch_bounds__(256) void scan_tiles_weighted_kernel(const uint32_t
 // h-fst.py:203-240 and tj_d.py:53-65 on the exact pair sums.
 __global__ void scan_finalize_kernel(const TilePartial *__restrict__ parts, const WinDesc *__restrict__ wins,
                                      uint64_t n_windows, PopSizes ps, const double *__restrict__ taj, int d_pi_mode,
-                                     int s_scope, int weighted, impop_window_stats *__restrict__ out) {
+                                     int s_scope, impop_window_stats *__restrict__ out) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_windows) return;
     const WinDesc w = wins[i];
     uint32_t s_all = 0, s_p = 0, s_a = 0, s_b = 0;
-    uint64_t sum_p = 0, sum_a = 0, sum_b = 0, sum_ab = 0, sum_w = 0;
+    uint64_t sum_p = 0, sum_a = 0, sum_b = 0, sum_ab = 0;
     for (uint64_t t = w.t0; t < w.t1; ++t) {
         const TilePartial p = parts[t];
         s_all += p.s_all; s_p += p.s_p; s_a += p.s_a; s_b += p.s_b;
         sum_p += p.sum_p; sum_a += p.sum_a; sum_b += p.sum_b; sum_ab += p.sum_ab;
-        if (weighted) sum_w += p.sum_w;
     }
-    const uint64_t n_sites = weighted ? sum_w : w.n_sites;  // weighted: W = sum of the window's site weights
+    const uint64_t n_sites = w.n_sites;  // window length, or the sum of its columns' weights (window_weights)
     impop_window_stats r;
     r.n_sites = (uint32_t)n_sites;
     r.s_all = s_all; r.s_p = s_p; r.s_a = s_a; r.s_b = s_b; r.flags = 0;
@@ -440,7 +437,8 @@ template <int K>
 __global__ __launch_bounds__(256) void scan_multi_kernel(const uint32_t *__restrict__ sb, const ScanTile *__restrict__ tiles,
                                                          const uint32_t *__restrict__ masks /* K x wps */,
                                                          const uint32_t *__restrict__ pop_n /* K */, uint32_t wps,
-                                                         uint32_t G, uint32_t r, uint64_t *__restrict__ out) {
+                                                         uint32_t G, uint32_t r, const uint32_t *__restrict__ weights /* nullable */,
+                                                         uint64_t *__restrict__ out) {
     constexpr int NP = K * (K - 1) / 2;
     __shared__ uint64_t red[4][K + NP];
     const ScanTile t = tiles[blockIdx.x];
@@ -473,12 +471,13 @@ __global__ __launch_bounds__(256) void scan_multi_kernel(const uint32_t *__restr
         }
         const uint64_t s = b * 64 + lane;
         if (s >= t.site_begin && s < t.site_end) {
+            const uint64_t wt = weights ? weights[s] : 1;  // wave-uniform choice
             int pi = K;
 #pragma unroll
             for (int k = 0; k < K; ++k) {
-                acc[k] += c[k] * (nk[k] - c[k]);
+                acc[k] += wt * (c[k] * (nk[k] - c[k]));
 #pragma unroll
-                for (int l = k + 1; l < K; ++l) acc[pi++] += c[k] * (nk[l] - c[l]) + c[l] * (nk[k] - c[k]);
+                for (int l = k + 1; l < K; ++l) acc[pi++] += wt * (c[k] * (nk[l] - c[l]) + c[l] * (nk[k] - c[k]));
             }
         }
     }
@@ -654,6 +653,14 @@ struct impop_scan_plan {
     size_t events_used = 0;
 };
 
+// W of every window in ORIGINAL coordinates: its length, or the sum of its columns' weights
+static void window_weights(const impop_matrix *m, const impop_window *windows, uint64_t n_windows, std::vector<WinDesc> &wd) {
+    for (uint64_t i = 0; i < n_windows; ++i) {
+        if (!m->wt_prefix.empty()) wd[i].n_sites = m->wt_prefix[windows[i].site_end] - m->wt_prefix[windows[i].site_begin];
+        else if (m->compact) wd[i].n_sites = windows[i].site_end - windows[i].site_begin;
+    }
+}
+
 // Default tile: ~256 KB of matrix per workgroup, but never so large that a small job leaves CUs without
 // work (>= 16 tiles per CU wanted), and never below the 32 blocks the kernel was tuned with.
 static uint32_t default_tile_blocks(const impop_ctx *ctx, const impop_matrix *m, const impop_window *windows, uint64_t n_windows) {
@@ -747,9 +754,7 @@ IMPOP_API int impop_scan_plan_create(impop_ctx *ctx, const impop_matrix *m, cons
         std::vector<impop_window> mapped;  // compacted matrix: original coordinates -> kept-site index ranges
         map_windows(m, windows, n_windows, mapped);
         build_tiles(mapped.data(), n_windows, tile_blocks, wps, tiles, wd, p->bytes_streamed);
-        for (uint64_t i = 0; m->compact && i < n_windows; ++i)
-            wd[i].n_sites = m->wt_prefix.empty() ? windows[i].site_end - windows[i].site_begin
-                                                 : m->wt_prefix[windows[i].site_end] - m->wt_prefix[windows[i].site_begin];
+        window_weights(m, windows, n_windows, wd);
     }
     p->n_tiles = tiles.size();
     auto fail = [&](int code) {
@@ -810,10 +815,7 @@ IMPOP_API int impop_scan_plan_launch(impop_scan_plan *p, void *d_out) {
         p->events_used++;
         HIP_TRY(hipEventRecord(ev0, st));
     }
-    // weights on the matrix, or a weighted matrix that was compacted (then even a window without any kept column
-    // has W = the sum of its original weights, which the plan took from the host prefix sums)
-    const bool weighted = p->m->d_wt != nullptr || !p->m->wt_prefix.empty();
-    const bool w_from_tiles = weighted && !p->m->compact;
+    const bool weighted = !p->m->wt_prefix.empty();  // W of each window came from the host prefix sums at plan time
     if (p->n_tiles && weighted) {
         hipLaunchKernelGGL(scan_tiles_weighted_kernel, dim3((uint32_t)p->n_tiles), dim3(256), 0, st, p->m->d_sb, p->d_tiles,
                            p->d_masks, p->m->g.wps, p->m->g.G, p->m->g.r, p->ps, p->m->d_wt, p->d_parts);
@@ -835,7 +837,7 @@ IMPOP_API int impop_scan_plan_launch(impop_scan_plan *p, void *d_out) {
     if (p->n_windows) {
         impop_window_stats *dst = d_out ? (impop_window_stats *)d_out : p->d_out;
         hipLaunchKernelGGL(scan_finalize_kernel, dim3((uint32_t)((p->n_windows + 127) / 128)), dim3(128), 0, st, p->d_parts,
-                           p->d_wins, p->n_windows, p->ps, ctx->d_taj, p->d_pi_mode, p->s_scope, w_from_tiles ? 1 : 0, dst);
+                           p->d_wins, p->n_windows, p->ps, ctx->d_taj, p->d_pi_mode, p->s_scope, dst);
         HIP_TRY(hipGetLastError());
     }
     return IMPOP_OK;
@@ -940,13 +942,12 @@ template <int K>
 static void launch_multi(hipStream_t st, const impop_matrix *m, uint64_t n_tiles, const ScanTile *d_tiles, const uint32_t *d_masks,
                          const uint32_t *d_n, uint64_t *d_parts) {
     hipLaunchKernelGGL((scan_multi_kernel<K>), dim3((uint32_t)n_tiles), dim3(256), 0, st, m->d_sb, d_tiles, d_masks, d_n, m->g.wps,
-                       m->g.G, m->g.r, d_parts);
+                       m->g.G, m->g.r, m->d_wt, d_parts);
 }
 
 IMPOP_API int impop_scan_multi(impop_ctx *ctx, const impop_matrix *m, const impop_window *windows, uint64_t n_windows,
                                const uint64_t *masks, uint32_t n_pop, impop_pair_stats *out_host) {
     REQUIRE(ctx && m, "impop_scan_multi: NULL argument");
-    NOT_WEIGHTED(m, "impop_scan_multi");
     REQUIRE(n_pop >= 2 && n_pop <= 8, "impop_scan_multi: n_pop must be 2..8");
     REQUIRE(masks, "impop_scan_multi: masks is NULL");
     REQUIRE(m->g.n_hap <= 65535, "impop_scan_multi: n_hap > 65535 not supported");
@@ -980,7 +981,7 @@ IMPOP_API int impop_scan_multi(impop_ctx *ctx, const impop_matrix *m, const impo
         map_windows(m, windows, n_windows, mapped);
         build_tiles(mapped.data(), n_windows, default_tile_blocks(ctx, m, windows, n_windows), wps, tiles, wd, bytes);
 
-        for (uint64_t i = 0; m->compact && i < n_windows; ++i) wd[i].n_sites = windows[i].site_end - windows[i].site_begin;
+        window_weights(m, windows, n_windows, wd);
     }
     REQUIRE(tiles.size() < 0x7FFFFFFFull, "impop_scan_multi: too many tiles");
     const size_t nt = tiles.size();

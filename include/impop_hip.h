@@ -98,7 +98,8 @@ int impop_matrix_download(impop_ctx *ctx, const impop_matrix *m, uint64_t site_b
  * impop_scan_plan_* then return sum_s w_s c(n-c) sums and n_sites = sum_s w_s over the window — the
  * records of the bp-expanded matrix — while s_all / s_p / s_a / s_b keep counting COLUMNS (variable nodes,
  * what a VCF of the window lists, run_tajd.sh:148).  impop_matrix_compact keeps the weights (a window's W stays
- * the sum over all its original columns).  Not combinable with impop_scan_multi or the all-pairs path
+ * the sum over all its original columns); impop_scan_multi honours them too.  Set them before building plans
+ * (refused while plans of this matrix are alive).  The all-pairs path refuses weighted matrices
  * (IMPOP_E_UNSUPPORTED). */
 int impop_matrix_set_site_weights(impop_ctx *ctx, impop_matrix *m, const uint32_t *weights_host);
 

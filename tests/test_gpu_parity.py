@@ -861,8 +861,13 @@ def test_weighted_sites_equal_bp_expanded_matrix(ctx, oracle):
             for mode in (0, 1, 2):
                 assert cw.scan(wn, mp, inA, inB, d_pi_mode=mode).tobytes() == bn.scan(wn, mp, inA, inB, d_pi_mode=mode).tobytes()
         cw.free()
+        # K-population scan with weights == the expanded matrix; the all-pairs path refuses weights
+        pops = [inA & ~inB, inB & ~inA, (1 - (inA | inB)).astype(np.uint8)]
+        assert bn.scan_multi(wn, pops).tobytes() == be.scan_multi(we, pops).tobytes()
+        plan = bn.plan(wn)
         with pytest.raises(ImpopError):
-            bn.scan_multi(wn, [inA & ~inB, inB & ~inA])
+            bn.set_site_weights(length)  # a live plan carries the windows' weights
+        plan.destroy()
         bn.set_site_weights(None)  # weights removed: plain node-level scan again
         assert int(bn.scan([wn[0]])[0]["n_sites"]) == K
         bn.free(); be.free()

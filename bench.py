@@ -185,6 +185,23 @@ def cpu_baseline(bm, windows, in_a, in_b, budget_s=12.0):
         py_rec = ref_style.window_chain(names, sim, in_a, in_b, int(w["seq_len"]), S)
         t_py += time.perf_counter() - t0
         n_py += 1
+    # ... and the same chain the way the reference scales today: a process per window over all host cores
+    py_mp = None
+    try:
+        import subprocess
+        import tempfile
+        with tempfile.TemporaryDirectory() as td:
+            k = min(4, len(windows))
+            stack = np.stack([bm.download(int(windows[i]["site_begin"]), int(windows[i]["site_end"])) for i in range(k)])
+            np.savez(os.path.join(td, "w.npz"), bits=stack, n=np.int64(n), W=np.int64(Wn), in_a=in_a, in_b=in_b)
+            r = subprocess.run([sys.executable, "-m", "oracle.ref_style_mp", os.path.join(td, "w.npz"), str(cores)], cwd=ROOT,
+                               capture_output=True, text=True, timeout=300)
+            if r.returncode == 0:
+                py_mp = json.loads(r.stdout.strip().splitlines()[-1])
+            else:
+                py_mp = {"error": r.stderr[-300:]}
+    except Exception as e:  # a secondary figure must not take the bench line down
+        py_mp = {"error": repr(e)}
     return {
         "value": n_all / t_all if t_all > 0 else None, "unit": "windows/s", "cores": 1, "kind": "port",
         "reference_style_python": {"value": n_py / t_py if t_py > 0 else None, "unit": "windows/s", "cores": 1,
@@ -195,6 +212,7 @@ def cpu_baseline(bm, windows, in_a, in_b, budget_s=12.0):
         "sitecount_port": {"value": n_sc / t_sc if t_sc > 0 else None, "unit": "windows/s", "cores": 1,
                            "sample": f"{n_sc} windows, oracle_site_scan_sitemajor (integer sums only), {t_sc:.1f} s"},
         "sitecount_port_allcores": mt,
+        "reference_style_python_allcores": py_mp,
         "reference_python_measured_in_build_container": "0.67-0.91 s/window for pica2.py alone (BASELINE.md §2)",
     }, first
 

@@ -261,14 +261,29 @@ def main():
     # communicator + all_gather_into_tensor path can be exercised on a one-GPU box
     use_dist = world > 1 or os.environ.get("IMPOP_BENCH_FORCE_DIST") == "1"
     if use_dist:
+        # The rendezvous comes from the launcher (torch.distributed.run exports MASTER_ADDR / MASTER_PORT).  Only the
+        # one-rank rehearsal without a launcher has to invent one: a port the kernel hands out, never a fixed
+        # number two jobs on one node could share.
+        if "MASTER_PORT" not in os.environ:
+            if world > 1:
+                log("bench.py: WORLD_SIZE > 1 but MASTER_PORT is not set; launch with torch.distributed.run")
+                sys.exit(2)
+            import socket
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29533")
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group("gloo", rank=rank, world_size=world)
 
-    stream = torch.cuda.current_stream(dev)
+    # ONE explicit stream carries everything: the scan kernels (the engine context is built on it), the
+    # collective's pre-event (RCCL waits for the work that is on the CURRENT stream when the collective is
+    # issued) and work.wait() (makes the CURRENT stream wait for the collective).  torch's default stream has
+    # handle 0, which the C ABI reads as "create a private stream" — that would leave scan and gather unordered.
+    stream = torch.cuda.Stream(dev)
+    assert stream.cuda_stream != 0
     ctx = impop_amd.Context(local_rank, stream=stream.cuda_stream)
     n, W, NW = args.n_hap, args.window, args.n_windows
     n_site = W * NW
@@ -282,37 +297,65 @@ def main():
     in_a = np.zeros(n, np.uint8); in_a[: min(140, n)] = 1
     in_b = np.zeros(n, np.uint8); in_b[min(140, n): min(240, n)] = 1
     plan = bm.plan(windows, None, in_a, in_b, tile_blocks=args.tile_blocks)
-    # double-buffered records: the all-gather of step i (RCCL stream) overlaps the scan of step i+1
-    # (compute stream); a buffer is rewritten only after its previous gather has been waited for
-    bufs = [torch.empty(NW * 128, dtype=torch.uint8, device=dev) for _ in range(2)]
-    gdev = dev if backend == "nccl" else torch.device("cpu")
-    gathered = [torch.empty(world * NW * 128, dtype=torch.uint8, device=gdev) for _ in range(2)] if use_dist else None
+    # double-buffered records: the all-gather of step i (RCCL's stream) overlaps the scan of step i+1
+    # (our stream); a buffer is rewritten only after its previous gather has been waited for
+    with torch.cuda.stream(stream):
+        bufs = [torch.empty(NW * 128, dtype=torch.uint8, device=dev) for _ in range(2)]
+        gdev = dev if backend == "nccl" else torch.device("cpu")
+        gathered = [torch.empty(world * NW * 128, dtype=torch.uint8, device=gdev) for _ in range(2)] if use_dist else None
     works = [None, None]
     counter = [0]
+    # exposed gather time: events on OUR stream around work.wait() — the time the scan stream stood still
+    # because a gather had not finished (0 when the collective hides behind the next scan)
+    wait_events = []
+    host_gather_s = [0.0]
 
-    def step():
+    def wait_for(b, timed):
+        if works[b] is None:
+            return
+        if timed and backend == "nccl":
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(stream)
+            works[b].wait()
+            e1.record(stream)
+            wait_events.append((e0, e1))
+        else:
+            works[b].wait()
+        works[b] = None
+
+    def step(timed=False):
         b = counter[0] & 1
         counter[0] += 1
-        if works[b] is not None:
-            works[b].wait()
-        plan.launch(bufs[b].data_ptr())
-        if use_dist:
-            works[b] = dist.all_gather_into_tensor(gathered[b], bufs[b] if backend == "nccl" else bufs[b].cpu(), async_op=True)
+        with torch.cuda.stream(stream):
+            wait_for(b, timed)
+            plan.launch(bufs[b].data_ptr())
+            if use_dist:
+                th = time.perf_counter()
+                if backend == "nccl":
+                    works[b] = dist.all_gather_into_tensor(gathered[b], bufs[b], async_op=True)
+                else:  # rehearsal: .cpu() is ordered on `stream` behind the scan and blocks the host
+                    works[b] = dist.all_gather_into_tensor(gathered[b], bufs[b].cpu(), async_op=True)
+                host_gather_s[0] += time.perf_counter() - th
 
-    def drain():
-        for b in (0, 1):
-            if works[b] is not None:
-                works[b].wait()
-                works[b] = None
+    def drain(timed=False):
+        with torch.cuda.stream(stream):
+            for b in (0, 1):
+                wait_for(b, timed)
         torch.cuda.synchronize(dev)
+
+    def check_gathered(b, what):
+        """every rank must hold every rank's records after the gather; its own slice is checkable locally"""
+        mine = bufs[b].cpu().numpy().tobytes()
+        allrec = gathered[b].cpu().numpy().tobytes()
+        assert allrec[rank * NW * 128: (rank + 1) * NW * 128] == mine, f"rank {rank}: gathered records differ from local ({what})"
+        return mine
 
     # ---- parity gate before timing (rank 0): GPU records vs the CPU oracle on sampled windows
     step()
     drain()
     recs = np.frombuffer(bufs[0].cpu().numpy().tobytes(), dtype=impop_amd.STATS_DTYPE)
-    if use_dist:  # every rank must hold every rank's records after the gather
-        allrec = np.frombuffer(gathered[0].cpu().numpy().tobytes(), dtype=impop_amd.STATS_DTYPE)
-        assert allrec[rank * NW: (rank + 1) * NW].tobytes() == recs.tobytes()
+    if use_dist:
+        check_gathered(0, "first step")
     cpu, first = None, None
     if rank == 0:
         from oracle import oracle as orc
@@ -335,26 +378,48 @@ def main():
         step()
     drain()
     plan.timing(True)
+    host_gather_s[0] = 0.0
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step()
-    drain()
+        step(timed=True)
+    drain(timed=True)
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize(dev)
     elapsed = time.perf_counter() - t0
     kern_ms, launches = plan.elapsed()
     plan.timing(False)
+    diag = None
     if use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=gdev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        k = torch.tensor([kern_ms], dtype=torch.float64, device=gdev)
-        dist.all_reduce(k, op=dist.ReduceOp.MAX)
-        kern_ms = float(k.item())
+        # the records gathered by the TIMED steps (both buffers) must be the ones this rank computed
+        for b in (0, 1):
+            if args.steps > b:
+                mine = check_gathered(b, "timed steps")
+                assert mine == recs.tobytes(), f"rank {rank}: records of a timed step differ from the gated first step"
+        exposed_ms = sum(e0.elapsed_time(e1) for e0, e1 in wait_events)
+        mine = torch.tensor([elapsed, kern_ms / max(launches, 1), exposed_ms / max(args.steps, 1),
+                             host_gather_s[0] * 1e3 / max(args.steps, 1)], dtype=torch.float64, device=gdev)
+        per_rank = torch.empty(world * 4, dtype=torch.float64, device=gdev)
+        dist.all_gather_into_tensor(per_rank, mine)
+        per_rank = per_rank.cpu().numpy().reshape(world, 4)
+        elapsed = float(per_rank[:, 0].max())
+        kern_ms = float(per_rank[:, 1].max()) * max(launches, 1)
+        diag = {"backend": "rccl" if backend == "nccl" else "gloo-rehearsal",
+                "elapsed_s_min": float(per_rank[:, 0].min()), "elapsed_s_max": float(per_rank[:, 0].max()),
+                "kernel_ms_avg_min": float(per_rank[:, 1].min()), "kernel_ms_avg_max": float(per_rank[:, 1].max()),
+                "kernel_ms_avg_per_rank": [float(x) for x in per_rank[:, 1]],
+                "gather_exposed_ms_per_step_max": float(per_rank[:, 2].max()),
+                "gather_issue_host_ms_per_step_max": float(per_rank[:, 3].max()),
+                "gather_bytes_per_rank": NW * 128, "gathered_records_checked": True}
+    else:
+        diag = {"backend": None, "elapsed_s_min": elapsed, "elapsed_s_max": elapsed,
+                "kernel_ms_avg_min": kern_ms / max(launches, 1), "kernel_ms_avg_max": kern_ms / max(launches, 1),
+                "kernel_ms_avg_per_rank": [kern_ms / max(launches, 1)],
+                "gather_exposed_ms_per_step_max": 0.0, "gather_issue_host_ms_per_step_max": 0.0,
+                "gather_bytes_per_rank": 0, "gathered_records_checked": False}
 
     secondary = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -385,6 +450,7 @@ def main():
                          "algorithmic_bytes_per_launch": algo_bytes, "layout_bytes_per_launch": plan.bytes_streamed,
                          "layout_GBps": plan.bytes_streamed / avg_kern_s / 1e9},
             "cpu_baseline": cpu,
+            "ranks": diag,
             "secondary": secondary,
         }
         print(json.dumps(out), flush=True)

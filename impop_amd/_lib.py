@@ -21,6 +21,7 @@ class ImpopError(RuntimeError):
         self.message = message
 
 
+ABI_VERSION = 2  # IMPOP_ABI_VERSION of include/impop_hip.h
 E_INVALID, E_NODEVICE, E_HIP, E_NOMEM, E_UNSUPPORTED = -1, -2, -3, -4, -5
 KEEP_SITE_BLOCKED, KEEP_HAP_MAJOR = 1, 2
 IDENTITY_MATCH, IDENTITY_DICE = 0, 1
@@ -67,6 +68,10 @@ class PairwiseStats(C.Structure):
                 ("n_sites", C.c_uint32), ("reserved", C.c_uint64)]
 
 
+class Pica2Detail(C.Structure):
+    _fields_ = [("sum_2pairs", C.c_double), ("n_pairs_with_data", C.c_uint64)]
+
+
 assert C.sizeof(WindowStats) == 128 and C.sizeof(Window) == 24 and C.sizeof(PairwiseStats) == 96
 
 _vp = C.c_void_p
@@ -109,19 +114,23 @@ SIGNATURES = {
     "impop_pairwise_identity": (C.c_int, [_vp, _vp, C.c_uint64, C.c_uint64, C.c_int, _f64p]),
     "impop_pairwise_scan": (C.c_int, [_vp, _vp, C.POINTER(Window), C.c_uint64, _u64p, _u64p, _u64p,
                                       C.POINTER(PairwiseParams), C.POINTER(PairwiseStats)]),
-    "impop_pi_from_identity": (C.c_int, [_vp, _f64p, C.c_uint32, C.c_double, C.c_int, C.c_uint64, _f64p, _f64p, _u32p, _u32p]),
+    "impop_pi_from_identity": (C.c_int, [_vp, _f64p, C.c_uint32, C.c_double, C.c_int, C.c_uint64, _u32p, _f64p, _f64p, _u32p, _u32p,
+                                         C.POINTER(Pica2Detail)]),
+    "impop_pica2_pair_terms": (C.c_int, [_vp, _f64p, C.c_uint32, C.c_int, _u32p, _u32p, C.c_uint32, _f64p, _f64p]),
     "impop_fst_from_identity": (C.c_int, [_vp, _f64p, C.c_uint32, _u8p, _u8p, C.c_uint64, C.c_int, _f64p, _u64p]),
     "impop_matrix_set_site_weights": (C.c_int, [_vp, _vp, _u32p]),
     "impop_matrix_compact": (C.c_int, [_vp, _vp, C.POINTER(_vp)]),
     "impop_matrix_positions": (C.c_int, [_vp, C.c_uint64, C.c_uint64, _u64p, _u64p]),
     "impop_ehh": (C.c_int, [_vp, _vp, C.c_uint64, C.c_uint64, _u64p, C.c_int, _f64p, _u32p]),
-    "impop_fst_grouped_from_identity": (C.c_int, [_vp, _f64p, C.c_uint32, _u8p, _u8p, C.c_double, C.c_uint64, C.c_int, _f64p, _u64p]),
+    "impop_fst_grouped_from_identity": (C.c_int, [_vp, _f64p, C.c_uint32, _u8p, _u8p, C.c_double, C.c_uint64, C.c_int, _u32p, _f64p,
+                                                  _u64p]),
     "impop_tajimas_d": (C.c_int, [_vp, _i64p, _f64p, _f64p, C.c_uint64, _f64p, _f64p]),
     "impop_cluster_from_identity": (C.c_int, [_vp, _f64p, C.c_uint32, C.c_double, _u32p, _u32p, _u32p]),
     "impop_py_round": (C.c_int, [_vp, _f64p, C.c_uint64, C.c_int, _f64p]),
     "impop_sim_parse": (C.c_int, [C.c_char_p, C.c_int, C.POINTER(_vp)]),
     "impop_sim_info": (C.c_int, [_vp, _u32p, _u64p, _u64p, _i64p, _u64p]),
     "impop_sim_names": (C.c_int, [_vp, C.c_char_p]),
+    "impop_sim_first_seen": (C.c_int, [_vp, _u32p]),
     "impop_sim_bad_text": (C.c_int, [_vp, C.c_char_p, C.c_size_t]),
     "impop_sim_dense": (C.c_int, [_vp, _f64p]),
     "impop_sim_free": (C.c_int, [_vp]),
@@ -163,8 +172,8 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)  # AttributeError if an export is missing
         fn.restype = res
         fn.argtypes = args
-    if lib.impop_version() != 1:
-        raise ImpopError(E_UNSUPPORTED, f"ABI version {lib.impop_version()} != 1")
+    if lib.impop_version() != ABI_VERSION:
+        raise ImpopError(E_UNSUPPORTED, f"ABI version {lib.impop_version()} != {ABI_VERSION}")
     _lib = lib
     return lib
 

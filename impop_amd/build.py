@@ -22,26 +22,56 @@ FLAGS = [
 ]
 
 
-def _stale() -> bool:
-    if not os.path.exists(SO):
-        return True
-    t = os.path.getmtime(SO)
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, "..", "include", "impop_hip.h")]
-    return any(os.path.getmtime(d) > t for d in deps)
+OBJ_DIR = os.path.join(HERE, "_obj")  # per-source objects (git-ignored *.o); only stale ones are recompiled
+LINK_LIBS = []
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
-    if not force and not _stale():
-        return SO
-    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-    if not os.path.exists(hipcc):
-        raise RuntimeError("hipcc not found: cannot build libimpop_hip.so")
-    cmd = [hipcc] + FLAGS + ["-o", SO + ".tmp"] + [os.path.join(CSRC, s) for s in SOURCES]
+def _headers_mtime() -> float:
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    deps.append(os.path.join(HERE, "..", "include", "impop_hip.h"))
+    deps.append(os.path.abspath(__file__))
+    return max(os.path.getmtime(d) for d in deps)
+
+
+def _compile_one(args):
+    hipcc, src, obj, verbose = args
+    cmd = [hipcc] + [f for f in FLAGS if f != "-shared"] + ["-c", "-o", obj + ".tmp", src]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
-        raise RuntimeError("hipcc failed:\n" + r.stdout + r.stderr)
+        return src, r.stdout + r.stderr
+    os.replace(obj + ".tmp", obj)
+    return src, None
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    hdr_t = _headers_mtime()
+    jobs, objs = [], []
+    for s in SOURCES:
+        src = os.path.join(CSRC, s)
+        obj = os.path.join(OBJ_DIR, os.path.splitext(s)[0] + ".o")
+        objs.append(obj)
+        if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), hdr_t):
+            jobs.append((hipcc, src, obj, verbose))
+    if not jobs and os.path.exists(SO) and os.path.getmtime(SO) >= max(os.path.getmtime(o) for o in objs):
+        return SO
+    if not os.path.exists(hipcc):
+        raise RuntimeError("hipcc not found: cannot build libimpop_hip.so")
+    if jobs:
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=min(len(jobs), max((os.cpu_count() or 2) - 1, 1))) as ex:
+            for src, err in ex.map(_compile_one, jobs):
+                if err is not None:
+                    raise RuntimeError(f"hipcc failed on {src}:\n{err}")
+    cmd = [hipcc, "-shared", "-fPIC", "--offload-arch=gfx950", "-fvisibility=hidden", "-o", SO + ".tmp"] + objs + LINK_LIBS
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("link failed:\n" + r.stdout + r.stderr)
     os.replace(SO + ".tmp", SO)
     return SO
 

@@ -922,10 +922,11 @@ IMPOP_API int impop_pairwise_scan(impop_ctx *ctx, const impop_matrix *m, const i
         b.gram = d_g; b.stride = (uint64_t)ld * ld; b.ld = ld; b.n = n; b.W = d_W; b.kind = params->identity_kind;
         b.round_digits = params->round_digits < 0 ? -1 : params->round_digits;
         b.seg_first = d_first; b.seg_count = d_count;
-        rc = launch_pica2(ctx, b, cnt, mask_p ? d_idx : nullptr, nP, params->threshold, d_L, d_p, nullptr);
+        rc = launch_pica2(ctx, b, cnt, mask_p ? d_idx : nullptr, nP, nullptr, params->threshold, d_L, d_p, nullptr);
         if (rc) return fail(rc);
         if (params->fst_method == 1)
-            rc = launch_hud_grouped(ctx, b, cnt, d_ia, (uint32_t)ia.size(), d_ib, (uint32_t)ib.size(), params->threshold, d_L, d_h);
+            rc = launch_hud_grouped(ctx, b, cnt, d_ia, (uint32_t)ia.size(), d_ib, (uint32_t)ib.size(), nullptr, nullptr, params->threshold,
+                                        d_L, d_h);
         else
             rc = launch_hfst(ctx, b, cnt, d_fa, d_fb, d_L, d_h);
         if (rc) return fail(rc);

@@ -247,6 +247,16 @@ IMPOP_API int impop_sim_names(const impop_sim *s, char *buf) {
     return IMPOP_OK;
 }
 
+// first_seen_out[k] = sorted rank of the k-th DISTINCT name in file order (group.a before group.b of a row):
+// the order in which the reference's reader adds names to its `elements` set (pica2.py:45-46), which decides
+// that set's iteration order and with it the seed order of pica2's greedy grouping
+IMPOP_API int impop_sim_first_seen(const impop_sim *s, uint32_t *first_seen_out) {
+    REQUIRE(s, "impop_sim_first_seen: handle is NULL");
+    REQUIRE(s->rank_of_id.empty() || first_seen_out, "impop_sim_first_seen: out is NULL");
+    for (size_t k = 0; k < s->rank_of_id.size(); ++k) first_seen_out[k] = s->rank_of_id[k];
+    return IMPOP_OK;
+}
+
 IMPOP_API int impop_sim_bad_text(const impop_sim *s, char *buf, size_t buflen) {
     REQUIRE(s && buf && buflen, "impop_sim_bad_text: bad arguments");
     snprintf(buf, buflen, "%s", s->bad_text.c_str());

@@ -34,43 +34,93 @@ __device__ inline uint64_t block_sum_u64(uint64_t v, uint64_t *sh) {
 }
 
 // ---------------------------------------------------------------------------------------
+// Greedy grouping shared by pica2 (pica2.py:94-112) and hud.py (hud.py:64-86): repeatedly take a seed from
+// the remaining elements and move every remaining element whose identity to the SEED exceeds the threshold
+// (strict >) into the seed's group.  The reference takes its seeds with set.pop(), i.e. in the iteration
+// order of `set(elements)`; `order` (nullable) is that order as element positions (order[k] = position in
+// 0..m of the k-th element the set iterates), nullptr = positions 0, 1, 2, ... (seed = smallest remaining
+// name).  Groups come out numbered the way the reference numbers them after `sorted(group)` / `groups.sort()`:
+// by their smallest member; rep[g] (nullable) = that member's position, gsz[g] = group size.
+// scratch: 2*m u32 of LDS the caller can spare during grouping (only touched when order != nullptr).
+// All threads of the workgroup call this; returns the number of groups.
+__device__ inline uint32_t greedy_groups(const SimView &S, const uint32_t *__restrict__ idx, uint32_t m, double thr,
+                                         const uint32_t *__restrict__ order, uint32_t *grp, uint32_t *gsz, uint32_t *rep,
+                                         uint32_t *scratch) {
+    __shared__ uint32_t chunk_cnt[ST];
+    const uint32_t tid = threadIdx.x;
+    for (uint32_t i = tid; i < m; i += ST) { grp[i] = NONE; gsz[i] = 0; }
+    __syncthreads();
+    uint32_t G = 0;
+    for (uint32_t k = 0; k < m; ++k) {
+        const uint32_t seed = order ? order[k] : k;
+        if (grp[seed] != NONE) continue;  // uniform across the workgroup
+        const uint32_t es = idx ? idx[seed] : seed;
+        uint32_t cnt = 0;
+        // without an order everything below the seed is already grouped
+        for (uint32_t o = (order ? 0 : seed + 1) + tid; o < m; o += ST) {
+            if (o == seed || grp[o] != NONE) continue;
+            const double v = sim_get(S, es, idx ? idx[o] : o);
+            if (v == v && v > thr) { grp[o] = G; ++cnt; }  // strict > (pica2.py:106, hud.py:80)
+        }
+        __syncthreads();  // every thread has tested grp[seed] and its own candidates before the seed is marked
+        if (tid == 0) { grp[seed] = G; ++cnt; if (rep) rep[G] = seed; }
+        if (cnt) atomicAdd(&gsz[G], cnt);
+        ++G;
+        __syncthreads();
+    }
+    if (!order) return G;  // seeds were the groups' smallest members, taken in increasing order: already sorted
+    // renumber by smallest member (pica2.py:110-112: sorted(group), groups.sort())
+    uint32_t *gmin = scratch, *newid = scratch + m;
+    for (uint32_t g = tid; g < G; g += ST) gmin[g] = NONE;
+    __syncthreads();
+    for (uint32_t i = tid; i < m; i += ST) atomicMin(&gmin[grp[i]], i);
+    __syncthreads();
+    // new id of a group = number of group minima at smaller positions: chunked count + scan over the threads
+    const uint32_t per = (m + ST - 1) / ST, lo = tid * per, hi = (lo + per < m) ? lo + per : m;
+    uint32_t c = 0;
+    for (uint32_t i = lo; i < hi; ++i) c += gmin[grp[i]] == i;
+    chunk_cnt[tid] = c;
+    __syncthreads();
+    uint32_t base = 0;
+    for (uint32_t t = 0; t < tid; ++t) base += chunk_cnt[t];
+    for (uint32_t i = lo; i < hi; ++i)
+        if (gmin[grp[i]] == i) newid[grp[i]] = base++;
+    __syncthreads();
+    for (uint32_t i = tid; i < m; i += ST) grp[i] = newid[grp[i]];
+    for (uint32_t g = tid; g < G; g += ST) gsz[g] = 0;
+    __syncthreads();
+    for (uint32_t i = tid; i < m; i += ST) atomicAdd(&gsz[grp[i]], 1u);
+    if (rep)
+        for (uint32_t g = tid; g < G; g += ST) rep[newid[g]] = gmin[g];
+    __syncthreads();
+    return G;
+}
+
+// ---------------------------------------------------------------------------------------
 // pica2.analyze_similarity_matrix (pica2.py:60-169).  Elements are idx[0..n_el) (or 0..n_el
-// when idx == nullptr), already in lexicographic name order.
-// dynamic LDS: grp[n_el] u32 | rep[n_el] u32 | gsz[n_el] u32 | rowsum[n_el] f64
+// when idx == nullptr), already in lexicographic name order; `order`: see greedy_groups.
+// dynamic LDS: rowsum[n_el] f64 (grouping scratch before step 2) | grp[n_el] u32 | rep[n_el] u32 | gsz[n_el] u32
 __global__ __launch_bounds__(ST) void pica2_kernel(SimBatch batch, const uint32_t *__restrict__ idx, uint32_t n_el,
-                                                   double threshold, const uint64_t *__restrict__ seq_len,
-                                                   Pica2Out *__restrict__ out, uint32_t *__restrict__ group_of) {
+                                                   const uint32_t *__restrict__ order, double threshold,
+                                                   const uint64_t *__restrict__ seq_len, Pica2Out *__restrict__ out,
+                                                   uint32_t *__restrict__ group_of) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     double *rowsum = reinterpret_cast<double *>(lds_raw);
     uint32_t *grp = reinterpret_cast<uint32_t *>(rowsum + n_el);
     uint32_t *rep = grp + n_el;
     uint32_t *gsz = rep + n_el;
     __shared__ uint32_t sh_have;
+    __shared__ uint64_t sh_npairs;
     const uint64_t prob = blockIdx.x;
     const SimView S = sim_view(batch, prob);  // no identity memo here: with few groups it costs more than it saves
     const uint32_t tid = threadIdx.x;
-    for (uint32_t i = tid; i < n_el; i += ST) { grp[i] = NONE; gsz[i] = 0; }
-    if (tid == 0) sh_have = 0;
-    __syncthreads();
-    // Step 1 (pica2.py:94-112): greedy groups, seed = smallest remaining element
-    uint32_t G = 0;
-    for (uint32_t seed = 0; seed < n_el; ++seed) {
-        if (grp[seed] != NONE) continue;  // uniform across the workgroup
-        const uint32_t es = idx ? idx[seed] : seed;
-        uint32_t cnt = 0;
-        if (tid == 0) { grp[seed] = G; rep[G] = seed; cnt = 1; }
-        for (uint32_t o = seed + 1 + tid; o < n_el; o += ST) {
-            if (grp[o] != NONE) continue;
-            const double v = sim_get(S, es, idx ? idx[o] : o);
-            if (v == v && v > threshold) { grp[o] = G; ++cnt; }  // strict > (pica2.py:106)
-        }
-        if (cnt) atomicAdd(&gsz[G], cnt);
-        ++G;
-        __syncthreads();
-    }
+    if (tid == 0) { sh_have = 0; sh_npairs = 0; }
+    // Step 1 (pica2.py:94-112)
+    const uint32_t G = greedy_groups(S, idx, n_el, threshold, order, grp, gsz, rep, reinterpret_cast<uint32_t *>(rowsum));
     // Step 2-3 (pica2.py:118-154): sum over group pairs of 2*(1-sim(rep_i,rep_j))*f_i*f_j
     const double total = (double)n_el;
     uint32_t have = 0;
+    uint64_t npairs = 0;
     for (uint32_t i = tid; i < G; i += ST) {
         const uint32_t ri = idx ? idx[rep[i]] : rep[i];
         const double fi = (double)gsz[i] / total;
@@ -82,10 +132,12 @@ __global__ __launch_bounds__(ST) void pica2_kernel(SimBatch batch, const uint32_
             const double pv = (1 - s) * fi * fj;
             acc += 2 * pv;
             have = 1;
+            ++npairs;
         }
         rowsum[i] = acc;
     }
     if (have) atomicOr(&sh_have, 1u);
+    if (npairs) atomicAdd((unsigned long long *)&sh_npairs, (unsigned long long)npairs);
     __syncthreads();
     if (tid == 0) {
         double acc = 0.0;
@@ -98,6 +150,7 @@ __global__ __launch_bounds__(ST) void pica2_kernel(SimBatch batch, const uint32_
         }
         Pica2Out o;
         o.pi = pi; o.pi_site = pi_site; o.n_groups = G; o.pad = 0;
+        o.sum_2pairs = acc; o.n_pairs = sh_npairs;
         out[prob] = o;
     }
     if (group_of)
@@ -190,27 +243,6 @@ __global__ __launch_bounds__(ST) void hfst_kernel(SimBatch batch, const uint8_t 
 // scripts/hudson/hud.py "grouped" Fst (hud.py:64-128, 173-300): greedy groups INSIDE each
 // population, frequency-weighted sums over group pairs with the first pair present in the table
 // (members in sorted order) as the groups' similarity.
-__device__ inline uint32_t hud_group(const SimView &S, const uint32_t *__restrict__ idx, uint32_t m, double thr,
-                                     uint32_t *grp, uint32_t *gsz) {
-    const uint32_t tid = threadIdx.x;
-    for (uint32_t i = tid; i < m; i += ST) { grp[i] = NONE; gsz[i] = 0; }
-    __syncthreads();
-    uint32_t G = 0;
-    for (uint32_t seed = 0; seed < m; ++seed) {
-        if (grp[seed] != NONE) continue;  // uniform
-        uint32_t cnt = 0;
-        if (tid == 0) { grp[seed] = G; cnt = 1; }
-        for (uint32_t o = seed + 1 + tid; o < m; o += ST) {
-            if (grp[o] != NONE) continue;
-            const double v = sim_get(S, idx[seed], idx[o]);
-            if (v == v && v > thr) { grp[o] = G; ++cnt; }  // hud.py:76-82
-        }
-        if (cnt) atomicAdd(&gsz[G], cnt);
-        ++G;
-        __syncthreads();
-    }
-    return G;
-}
 // hud.py:88-99 get_group_similarity: first (member of g1) x (member of g2) pair that is present
 __device__ inline double hud_first_found(const SimView &S, const uint32_t *ia, const uint32_t *ga, uint32_t ma, uint32_t g1,
                                          const uint32_t *ib, const uint32_t *gb, uint32_t mb, uint32_t g2) {
@@ -224,9 +256,12 @@ __device__ inline double hud_first_found(const SimView &S, const uint32_t *ia, c
     }
     return __builtin_nan("");
 }
-// dynamic LDS: rowsum[max(ma,mb)] f64 | grpA[ma] | szA[ma] | grpB[mb] | szB[mb]
+// order_a / order_b (nullable): seed orders inside A / B as positions into ia / ib (see greedy_groups)
+// dynamic LDS: rowsum[max(ma,mb)] f64 (grouping scratch first) | grpA[ma] | szA[ma] | grpB[mb] | szB[mb]
 __global__ __launch_bounds__(ST) void hud_grouped_kernel(SimBatch batch, const uint32_t *__restrict__ ia, uint32_t ma,
-                                                         const uint32_t *__restrict__ ib, uint32_t mb, double threshold,
+                                                         const uint32_t *__restrict__ ib, uint32_t mb,
+                                                         const uint32_t *__restrict__ order_a,
+                                                         const uint32_t *__restrict__ order_b, double threshold,
                                                          const uint64_t *__restrict__ seq_len, HfstOut *__restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     const uint32_t mx = ma > mb ? ma : mb;
@@ -238,8 +273,8 @@ __global__ __launch_bounds__(ST) void hud_grouped_kernel(SimBatch batch, const u
     const uint64_t prob = blockIdx.x;
     const SimView S = sim_view(batch, prob);
     const uint32_t tid = threadIdx.x;
-    const uint32_t GA = hud_group(S, ia, ma, threshold, grpA, szA);
-    const uint32_t GB = hud_group(S, ib, mb, threshold, grpB, szB);
+    const uint32_t GA = greedy_groups(S, ia, ma, threshold, order_a, grpA, szA, nullptr, reinterpret_cast<uint32_t *>(rowsum));
+    const uint32_t GB = greedy_groups(S, ib, mb, threshold, order_b, grpB, szB, nullptr, reinterpret_cast<uint32_t *>(rowsum));
     if (tid < 3) sh_miss[tid] = 0;
     __syncthreads();
     // within A, within B (hud.py:101-128), then between (hud.py:235-263): one pass each
@@ -387,15 +422,16 @@ __global__ void py_round_kernel(const double *__restrict__ x, uint64_t count, in
 }
 
 int launch_pica2(impop_ctx *ctx, const SimBatch &b, uint64_t n_problems, const uint32_t *d_idx, uint32_t n_el,
-                 double threshold, const uint64_t *d_seq_len, Pica2Out *d_out, uint32_t *d_group_of) {
+                 const uint32_t *d_order, double threshold, const uint64_t *d_seq_len, Pica2Out *d_out,
+                 uint32_t *d_group_of) {
     if (!n_problems) return IMPOP_OK;
     const size_t lds = (size_t)n_el * (8 + 12) + 16;
     REQUIRE(lds <= 150 * 1024, "pica2: %u elements exceed the LDS-resident grouping limit (7600)", n_el);
     REQUIRE(n_problems < 0x7FFFFFFFull, "pica2: too many problems");
     if (lds > 48 * 1024)
         HIP_TRY(hipFuncSetAttribute((const void *)pica2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(pica2_kernel, dim3((uint32_t)n_problems), dim3(ST), lds, ctx->stream, b, d_idx, n_el, threshold,
-                       d_seq_len, d_out, d_group_of);
+    hipLaunchKernelGGL(pica2_kernel, dim3((uint32_t)n_problems), dim3(ST), lds, ctx->stream, b, d_idx, n_el, d_order,
+                       threshold, d_seq_len, d_out, d_group_of);
     HIP_TRY(hipGetLastError());
     return IMPOP_OK;
 }
@@ -412,15 +448,16 @@ int launch_hfst(impop_ctx *ctx, const SimBatch &b, uint64_t n_problems, const ui
 }
 
 int launch_hud_grouped(impop_ctx *ctx, const SimBatch &b, uint64_t n_problems, const uint32_t *d_ia, uint32_t ma,
-                       const uint32_t *d_ib, uint32_t mb, double threshold, const uint64_t *d_seq_len, HfstOut *d_out) {
+                       const uint32_t *d_ib, uint32_t mb, const uint32_t *d_order_a, const uint32_t *d_order_b,
+                       double threshold, const uint64_t *d_seq_len, HfstOut *d_out) {
     if (!n_problems) return IMPOP_OK;
     REQUIRE(n_problems < 0x7FFFFFFFull, "grouped Fst: too many problems");
     const size_t lds = (size_t)std::max(ma, mb) * 8 + ((size_t)ma + mb) * 8 + 16;
     REQUIRE(lds <= 150 * 1024, "grouped Fst: populations too large for the LDS-resident grouping");
     if (lds > 48 * 1024)
         HIP_TRY(hipFuncSetAttribute((const void *)hud_grouped_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(hud_grouped_kernel, dim3((uint32_t)n_problems), dim3(ST), lds, ctx->stream, b, d_ia, ma, d_ib, mb, threshold,
-                       d_seq_len, d_out);
+    hipLaunchKernelGGL(hud_grouped_kernel, dim3((uint32_t)n_problems), dim3(ST), lds, ctx->stream, b, d_ia, ma, d_ib, mb,
+                       d_order_a, d_order_b, threshold, d_seq_len, d_out);
     HIP_TRY(hipGetLastError());
     return IMPOP_OK;
 }
@@ -468,38 +505,122 @@ static size_t carve_size(std::initializer_list<size_t> sizes) {
 
 using namespace impop;
 
+// seed_rank -> order (inverse permutation) restricted to `members` (positions 0..m of the member list);
+// ranks only need to be distinct among the members
+static int seed_order_of(const uint32_t *seed_rank, const std::vector<uint32_t> &members, std::vector<uint32_t> &order,
+                         const char *fn) {
+    const uint32_t m = (uint32_t)members.size();
+    order.resize(m);
+    for (uint32_t k = 0; k < m; ++k) order[k] = k;
+    std::stable_sort(order.begin(), order.end(),
+                     [&](uint32_t x, uint32_t y) { return seed_rank[members[x]] < seed_rank[members[y]]; });
+    for (uint32_t k = 1; k < m; ++k)
+        REQUIRE(seed_rank[members[order[k - 1]]] != seed_rank[members[order[k]]],
+                "%s: seed_rank must be distinct among the elements it orders (rank %u occurs twice)", fn,
+                seed_rank[members[order[k]]]);
+    return IMPOP_OK;
+}
+
 IMPOP_API int impop_pi_from_identity(impop_ctx *ctx, const double *ident, uint32_t n, double threshold, int round_digits,
-                                     uint64_t seq_len, double *pi, double *pi_site, uint32_t *group_of,
-                                     uint32_t *n_groups) {
+                                     uint64_t seq_len, const uint32_t *seed_rank, double *pi, double *pi_site,
+                                     uint32_t *group_of, uint32_t *n_groups, impop_pica2_detail *detail) {
     REQUIRE(ctx, "impop_pi_from_identity: ctx is NULL");
     REQUIRE(n == 0 || ident, "impop_pi_from_identity: ident is NULL");
     REQUIRE(round_digits <= 19, "impop_pi_from_identity: round_digits > 19 unsupported");
     HIP_TRY(hipSetDevice(ctx->device));
+    std::vector<uint32_t> order;
+    if (seed_rank && n) {
+        std::vector<uint32_t> all(n);
+        for (uint32_t i = 0; i < n; ++i) all[i] = i;
+        int rc0 = seed_order_of(seed_rank, all, order, "impop_pi_from_identity");
+        if (rc0) return rc0;
+    }
     const size_t nn = (size_t)n * n;
     void *d = nullptr;
-    int rc = ctx_scratch(ctx, carve_size({nn * 8, 8, sizeof(Pica2Out), (size_t)n * 4}), &d);
+    int rc = ctx_scratch(ctx, carve_size({nn * 8, 8, sizeof(Pica2Out), (size_t)n * 4, (size_t)n * 4}), &d);
     if (rc) return rc;
     Carve cv(d);
     double *d_id = cv.take<double>(nn ? nn : 1);
     uint64_t *d_L = cv.take<uint64_t>(1);
     Pica2Out *d_out = cv.take<Pica2Out>(1);
     uint32_t *d_grp = cv.take<uint32_t>(n ? n : 1);
+    uint32_t *d_order = cv.take<uint32_t>(n ? n : 1);
     if (nn) HIP_TRY(hipMemcpyAsync(d_id, ident, nn * 8, hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(hipMemcpyAsync(d_L, &seq_len, 8, hipMemcpyHostToDevice, ctx->stream));
+    if (!order.empty()) HIP_TRY(hipMemcpyAsync(d_order, order.data(), (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
     SimBatch b{};
     b.dense = d_id; b.gram = nullptr; b.stride = nn; b.ld = n; b.n = n; b.W = nullptr; b.kind = 0;
     b.round_digits = round_digits < 0 ? -1 : round_digits;
-    rc = launch_pica2(ctx, b, 1, nullptr, n, threshold, d_L, d_out, d_grp);
+    rc = launch_pica2(ctx, b, 1, nullptr, n, order.empty() ? nullptr : d_order, threshold, d_L, d_out, d_grp);
     if (rc) return rc;
     Pica2Out o;
     std::vector<uint32_t> g(n ? n : 1);
     HIP_TRY(hipMemcpyAsync(&o, d_out, sizeof o, hipMemcpyDeviceToHost, ctx->stream));
     if (n) HIP_TRY(hipMemcpyAsync(g.data(), d_grp, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));  // `order` (pageable) must outlive its copy
     if (pi) *pi = o.pi;
     if (pi_site) *pi_site = o.pi_site;
     if (n_groups) *n_groups = o.n_groups;
     if (group_of && n) memcpy(group_of, g.data(), (size_t)n * 4);
+    if (detail) { detail->sum_2pairs = o.sum_2pairs; detail->n_pairs_with_data = o.n_pairs; }
+    return IMPOP_OK;
+}
+
+// the "Step 2" table of pica2's log (pica2.py:125-145): for groups i < j, identity of the two representatives
+// (rounded like the analysis; NaN = pair absent, the line the reference replaces by a warning) and the term
+// (1 - sim) * f_i * f_j.  One thread per pair.
+__global__ void pica2_pairs_kernel(SimBatch batch, const uint32_t *__restrict__ rep, const uint32_t *__restrict__ gsz,
+                                   uint32_t G, uint32_t total, double *__restrict__ sims, double *__restrict__ values) {
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t np = (uint64_t)G * (G - 1) / 2;
+    if (t >= np) return;
+    // row i of the strict upper triangle: the largest i with i(2G-i-1)/2 <= t
+    uint32_t i = (uint32_t)(((2.0 * G - 1) - sqrt((2.0 * G - 1) * (2.0 * G - 1) - 8.0 * (double)t)) / 2.0);
+    while (i > 0 && (uint64_t)i * (2ull * G - i - 1) / 2 > t) --i;
+    while ((uint64_t)(i + 1) * (2ull * G - i - 2) / 2 <= t) ++i;
+    const uint32_t j = (uint32_t)(t - (uint64_t)i * (2ull * G - i - 1) / 2) + i + 1;
+    const SimView S = sim_view(batch, 0);
+    const double sv = sim_get(S, rep[i], rep[j]);
+    sims[t] = sv;
+    const double fi = (double)gsz[i] / (double)total, fj = (double)gsz[j] / (double)total;  // pica2.py:137-138
+    values[t] = (1 - sv) * fi * fj;                                                       // :139
+}
+
+IMPOP_API int impop_pica2_pair_terms(impop_ctx *ctx, const double *ident, uint32_t n, int round_digits,
+                                     const uint32_t *rep, const uint32_t *group_size, uint32_t n_groups,
+                                     double *sims_out, double *values_out) {
+    REQUIRE(ctx, "impop_pica2_pair_terms: ctx is NULL");
+    REQUIRE(round_digits <= 19, "impop_pica2_pair_terms: round_digits > 19 unsupported");
+    if (n_groups < 2) return IMPOP_OK;
+    REQUIRE(ident && rep && group_size && sims_out && values_out, "impop_pica2_pair_terms: NULL argument");
+    uint64_t total = 0;
+    for (uint32_t g = 0; g < n_groups; ++g) {
+        REQUIRE(rep[g] < n, "impop_pica2_pair_terms: representative %u out of range", rep[g]);
+        total += group_size[g];
+    }
+    REQUIRE(total > 0 && total <= 0xFFFFFFFFull, "impop_pica2_pair_terms: bad group sizes");
+    HIP_TRY(hipSetDevice(ctx->device));
+    const size_t nn = (size_t)n * n;
+    const uint64_t np = (uint64_t)n_groups * (n_groups - 1) / 2;
+    REQUIRE((np + 255) / 256 < 0x7FFFFFFFull, "impop_pica2_pair_terms: too many group pairs");
+    void *d = nullptr;
+    int rc = ctx_scratch(ctx, carve_size({nn * 8, (size_t)n_groups * 4, (size_t)n_groups * 4, np * 8, np * 8}), &d);
+    if (rc) return rc;
+    Carve cv(d);
+    double *d_id = cv.take<double>(nn);
+    uint32_t *d_rep = cv.take<uint32_t>(n_groups), *d_sz = cv.take<uint32_t>(n_groups);
+    double *d_s = cv.take<double>(np), *d_v = cv.take<double>(np);
+    HIP_TRY(hipMemcpyAsync(d_id, ident, nn * 8, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(d_rep, rep, (size_t)n_groups * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(d_sz, group_size, (size_t)n_groups * 4, hipMemcpyHostToDevice, ctx->stream));
+    SimBatch b{};
+    b.dense = d_id; b.stride = nn; b.ld = n; b.n = n; b.round_digits = round_digits < 0 ? -1 : round_digits;
+    hipLaunchKernelGGL(pica2_pairs_kernel, dim3((uint32_t)((np + 255) / 256)), dim3(256), 0, ctx->stream, b, d_rep, d_sz,
+                       n_groups, (uint32_t)total, d_s, d_v);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(sims_out, d_s, np * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(values_out, d_v, np * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
     return IMPOP_OK;
 }
 
@@ -629,7 +750,7 @@ IMPOP_API int impop_py_round(impop_ctx *ctx, const double *x, uint64_t count, in
 
 IMPOP_API int impop_fst_grouped_from_identity(impop_ctx *ctx, const double *ident, uint32_t n, const uint8_t *in_a,
                                               const uint8_t *in_b, double threshold, uint64_t seq_len, int round_digits,
-                                              double *out, uint64_t *counts) {
+                                              const uint32_t *seed_rank, double *out, uint64_t *counts) {
     REQUIRE(ctx && out, "impop_fst_grouped_from_identity: NULL argument");
     REQUIRE(n == 0 || (ident && in_a && in_b), "impop_fst_grouped_from_identity: NULL input");
     REQUIRE(round_digits <= 19, "impop_fst_grouped_from_identity: round_digits > 19 unsupported");
@@ -645,20 +766,31 @@ IMPOP_API int impop_fst_grouped_from_identity(impop_ctx *ctx, const double *iden
     REQUIRE(lds <= 150 * 1024, "grouped Fst: populations too large for the LDS-resident grouping");
     const size_t nn = (size_t)n * n;
     void *d = nullptr;
-    int rc = ctx_scratch(ctx, carve_size({nn * 8, 8, sizeof(HfstOut), (size_t)ma * 4, (size_t)mb * 4}), &d);
+    std::vector<uint32_t> oa, ob;
+    if (seed_rank) {
+        int rc0 = seed_order_of(seed_rank, ia, oa, "impop_fst_grouped_from_identity");
+        if (!rc0) rc0 = seed_order_of(seed_rank, ib, ob, "impop_fst_grouped_from_identity");
+        if (rc0) return rc0;
+    }
+    int rc = ctx_scratch(ctx, carve_size({nn * 8, 8, sizeof(HfstOut), (size_t)ma * 4, (size_t)mb * 4, (size_t)ma * 4,
+                                          (size_t)mb * 4}), &d);
     if (rc) return rc;
     Carve cv(d);
     double *d_id = cv.take<double>(nn ? nn : 1);
     uint64_t *d_L = cv.take<uint64_t>(1);
     HfstOut *d_out = cv.take<HfstOut>(1);
     uint32_t *d_ia = cv.take<uint32_t>(ma ? ma : 1), *d_ib = cv.take<uint32_t>(mb ? mb : 1);
+    uint32_t *d_oa = cv.take<uint32_t>(ma ? ma : 1), *d_ob = cv.take<uint32_t>(mb ? mb : 1);
+    if (!oa.empty()) HIP_TRY(hipMemcpyAsync(d_oa, oa.data(), (size_t)ma * 4, hipMemcpyHostToDevice, ctx->stream));
+    if (!ob.empty()) HIP_TRY(hipMemcpyAsync(d_ob, ob.data(), (size_t)mb * 4, hipMemcpyHostToDevice, ctx->stream));
     if (nn) HIP_TRY(hipMemcpyAsync(d_id, ident, nn * 8, hipMemcpyHostToDevice, ctx->stream));
     if (ma) HIP_TRY(hipMemcpyAsync(d_ia, ia.data(), (size_t)ma * 4, hipMemcpyHostToDevice, ctx->stream));
     if (mb) HIP_TRY(hipMemcpyAsync(d_ib, ib.data(), (size_t)mb * 4, hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(hipMemcpyAsync(d_L, &seq_len, 8, hipMemcpyHostToDevice, ctx->stream));
     SimBatch b{};
     b.dense = d_id; b.stride = nn; b.ld = n; b.n = n; b.round_digits = round_digits < 0 ? -1 : round_digits;
-    rc = launch_hud_grouped(ctx, b, 1, d_ia, ma, d_ib, mb, threshold, d_L, d_out);
+    rc = launch_hud_grouped(ctx, b, 1, d_ia, ma, d_ib, mb, oa.empty() ? nullptr : d_oa, ob.empty() ? nullptr : d_ob, threshold,
+                            d_L, d_out);
     if (rc) return rc;
     HfstOut o;
     HIP_TRY(hipMemcpyAsync(&o, d_out, sizeof o, hipMemcpyDeviceToHost, ctx->stream));

@@ -117,6 +117,8 @@ __device__ inline double sim_get(const SimView &S, uint32_t i, uint32_t j) {
 struct Pica2Out {
     double pi, pi_site;
     uint32_t n_groups, pad;
+    double sum_2pairs;   // sum(2 * pair for pair in group_pairs), pica2.py:154/159
+    uint64_t n_pairs;    // len(group_pairs), pica2.py:158
 };
 
 struct HfstOut {
@@ -124,13 +126,16 @@ struct HfstOut {
     uint64_t cnt[6];   // pairs_a, miss_a, pairs_b, miss_b, pairs_between, miss_between
 };
 
+// d_order (nullable): seed order of the greedy grouping as positions into the element list (stats.hip greedy_groups)
 int launch_pica2(impop_ctx *ctx, const SimBatch &b, uint64_t n_problems, const uint32_t *d_idx, uint32_t n_el,
-                 double threshold, const uint64_t *d_seq_len, Pica2Out *d_out, uint32_t *d_group_of);
+                 const uint32_t *d_order, double threshold, const uint64_t *d_seq_len, Pica2Out *d_out,
+                 uint32_t *d_group_of);
 int launch_hfst(impop_ctx *ctx, const SimBatch &b, uint64_t n_problems, const uint8_t *d_in_a, const uint8_t *d_in_b,
                 const uint64_t *d_seq_len, HfstOut *d_out);
 // hud.py grouped Fst: members of A / B as index lists (overlap already removed)
 int launch_hud_grouped(impop_ctx *ctx, const SimBatch &b, uint64_t n_problems, const uint32_t *d_ia, uint32_t ma,
-                       const uint32_t *d_ib, uint32_t mb, double threshold, const uint64_t *d_seq_len, HfstOut *d_out);
+                       const uint32_t *d_ib, uint32_t mb, const uint32_t *d_order_a, const uint32_t *d_order_b,
+                       double threshold, const uint64_t *d_seq_len, HfstOut *d_out);
 int launch_af(impop_ctx *ctx, const SimBatch &b, double threshold, uint32_t *d_adj, uint32_t *d_cluster_of,
               uint32_t *d_sizes, uint32_t *d_nclusters);
 

@@ -110,9 +110,17 @@ class Context:
     """One GPU + one HIP stream (impop_ctx)."""
 
     def __init__(self, device: int = 0, stream: Optional[int] = None):
+        """stream: None = the context creates its own non-blocking HIP stream; otherwise the integer handle
+        of an existing hipStream_t whose ordering the caller relies on (e.g. torch.cuda.Stream(dev).cuda_stream).
+        Handle 0 — HIP's legacy null stream, which is what torch's DEFAULT stream reports — is refused: the C
+        ABI reads NULL as "create a private stream", and silently doing that would leave the caller's
+        collectives / copies unordered with the scans."""
         self._lib = _lib.load()
         self._h = C.c_void_p()
-        check(self._lib.impop_ctx_create(int(device), C.c_void_p(stream) if stream else None, C.byref(self._h)))
+        if stream is not None and int(stream) == 0:
+            raise ValueError("Context(stream=0): the null stream cannot be adopted; pass stream=None for a private stream "
+                             "or the handle of an explicit stream (torch.cuda.Stream(dev).cuda_stream)")
+        check(self._lib.impop_ctx_create(int(device), C.c_void_p(int(stream)) if stream is not None else None, C.byref(self._h)))
         self.device = int(device)
 
     @property
@@ -170,16 +178,41 @@ class Context:
         return BitMatrix(self, h)
 
     # ---- statistics on a given identity matrix (the .sim drop-in path) -----------------
-    def pi_from_identity(self, ident: np.ndarray, threshold: float, round_digits: Optional[int], seq_len: Optional[int]):
+    def pi_from_identity(self, ident: np.ndarray, threshold: float, round_digits: Optional[int], seq_len: Optional[int],
+                         seed_rank=None, detail: bool = False):
+        """-> (pi, pi_site, group_of, n_groups[, (sum_2pairs, n_pairs_with_data)]).  seed_rank: see
+        impop_pi_from_identity (position of every element in the reference's set iteration order)."""
         a = np.ascontiguousarray(ident, dtype=np.float64)
         n = a.shape[0] if a.ndim == 2 else 0
         pi, ps, G = C.c_double(), C.c_double(), C.c_uint32()
         grp = np.zeros(max(n, 1), dtype=np.uint32)
+        sr = None if seed_rank is None else np.ascontiguousarray(seed_rank, dtype=np.uint32)
+        if sr is not None and sr.shape != (n,):
+            raise ValueError("seed_rank must have one entry per element")
+        det = _lib.Pica2Detail()
         check(self._lib.impop_pi_from_identity(self.handle, a.ctypes.data_as(C.POINTER(C.c_double)), n, float(threshold),
                                                -1 if round_digits is None else int(round_digits), int(seq_len or 0),
+                                               sr.ctypes.data_as(C.POINTER(C.c_uint32)) if sr is not None and n else None,
                                                C.byref(pi), C.byref(ps), grp.ctypes.data_as(C.POINTER(C.c_uint32)),
-                                               C.byref(G)))
-        return pi.value, ps.value, grp[:n].copy(), G.value
+                                               C.byref(G), C.byref(det)))
+        out = (pi.value, ps.value, grp[:n].copy(), G.value)
+        return out + ((det.sum_2pairs, int(det.n_pairs_with_data)),) if detail else out
+
+    def pica2_pair_terms(self, ident: np.ndarray, round_digits: Optional[int], rep, group_size):
+        """Identity of the representatives and (1 - sim) f_g f_h for every group pair g < h, row-major
+        (the Step 2 table of pica2's log, pica2.py:125-145)."""
+        a = np.ascontiguousarray(ident, dtype=np.float64)
+        n = a.shape[0] if a.ndim == 2 else 0
+        r = np.ascontiguousarray(rep, dtype=np.uint32)
+        z = np.ascontiguousarray(group_size, dtype=np.uint32)
+        G = len(r)
+        npair = G * (G - 1) // 2
+        sims, vals = np.zeros(max(npair, 1)), np.zeros(max(npair, 1))
+        check(self._lib.impop_pica2_pair_terms(self.handle, a.ctypes.data_as(C.POINTER(C.c_double)), n,
+                                               -1 if round_digits is None else int(round_digits),
+                                               r.ctypes.data_as(C.POINTER(C.c_uint32)), z.ctypes.data_as(C.POINTER(C.c_uint32)), G,
+                                               sims.ctypes.data_as(C.POINTER(C.c_double)), vals.ctypes.data_as(C.POINTER(C.c_double))))
+        return sims[:npair], vals[:npair]
 
     def fst_from_identity(self, ident: np.ndarray, in_a, in_b, seq_len: Optional[int], round_digits: Optional[int]):
         a = np.ascontiguousarray(ident, dtype=np.float64)
@@ -196,17 +229,21 @@ class Context:
         return out, cnt
 
     def fst_grouped_from_identity(self, ident: np.ndarray, in_a, in_b, threshold: float, seq_len: Optional[int],
-                                  round_digits: Optional[int]):
+                                  round_digits: Optional[int], seed_rank=None):
         a = np.ascontiguousarray(ident, dtype=np.float64)
         n = a.shape[0] if a.ndim == 2 else 0
         fa = np.ascontiguousarray(in_a, dtype=np.uint8)
         fb = np.ascontiguousarray(in_b, dtype=np.uint8)
         out = np.zeros(6)
         cnt = np.zeros(6, dtype=np.uint64)
+        sr = None if seed_rank is None else np.ascontiguousarray(seed_rank, dtype=np.uint32)
+        if sr is not None and sr.shape != (n,):
+            raise ValueError("seed_rank must have one entry per element")
         check(self._lib.impop_fst_grouped_from_identity(self.handle, a.ctypes.data_as(C.POINTER(C.c_double)), n,
                                                         fa.ctypes.data_as(C.POINTER(C.c_uint8)), fb.ctypes.data_as(C.POINTER(C.c_uint8)),
                                                         float(threshold), int(seq_len) if seq_len and seq_len > 0 else 0,
                                                         -1 if round_digits is None else int(round_digits),
+                                                        sr.ctypes.data_as(C.POINTER(C.c_uint32)) if sr is not None and n else None,
                                                         out.ctypes.data_as(C.POINTER(C.c_double)), cnt.ctypes.data_as(C.POINTER(C.c_uint64))))
         return out, cnt
 

@@ -42,7 +42,6 @@ def calculate_fst(similarities, pop_a, pop_b, sequence_length=None, round_digits
 
 def calculate_fst_dense(names, dense, pop_a, pop_b, sequence_length=None, round_digits=None, log_file=None, ctx=None):
     """calculate_fst on an already densified table (what the drop-in CLI calls after the native ingest)."""
-    log_print = _line_writer(log_file)
     overlap = pop_a & pop_b
     if overlap:  # h-fst.py:181-185
         print(f"Warning: {len(overlap)} sequences appear in both populations", file=sys.stderr)
@@ -59,17 +58,13 @@ def calculate_fst_dense(names, dense, pop_a, pop_b, sequence_length=None, round_
         big[:n0, :n0] = dense
         dense = big[np.ix_(order, order)]
         names = [names[i] for i in order]
-    L = sequence_length if (sequence_length and sequence_length > 0) else None
-    out, cnt = ctx.fst_from_identity(dense, _flags(names, pop_a), _flags(names, pop_b), L, round_digits)
-    log_print("FST Calculation")
-    log_print("=" * 50)
-    log_print(f"Population A: {len(pop_a)} sequences")
-    log_print(f"Population B: {len(pop_b)} sequences")
-    if round_digits is not None:
-        log_print(f"Rounding similarities to {round_digits} decimal places")
-    log_print(f"  pairs A = {int(cnt[0])} ({int(cnt[1])} missing), pairs B = {int(cnt[2])} ({int(cnt[3])} missing), "
-              f"pairs between = {int(cnt[4])} ({int(cnt[5])} missing)")
-    keys = ("fst", "pi_a", "pi_b", "pi_xy", "dxy", "da")
-    res = {k: float(v) for k, v in zip(keys, out)}
-    log_print(f"  FST = {res['fst']:.6f}")
-    return res
+    out, cnt = ctx.fst_from_identity(dense, _flags(names, pop_a), _flags(names, pop_b), None, round_digits)
+    fst, pi_a, pi_b, pi_xy, dxy = (float(x) for x in out[:5])
+    if log_file:  # h-fst.py:187-231: hud.py's direct-method text without the method lines
+        from .hud import _log_text
+        log_file.write(_log_text(None, None, round_digits, len(pop_a), len(pop_b), (fst, pi_a, pi_b, pi_xy, dxy),
+                                 [int(c) for c in cnt], sequence_length))
+    if sequence_length and sequence_length > 0:  # h-fst.py:233-240 (Fst itself is never divided)
+        return {"fst": fst, "pi_a": pi_a / sequence_length, "pi_b": pi_b / sequence_length, "pi_xy": pi_xy / sequence_length,
+                "dxy": dxy / sequence_length, "da": (dxy - pi_xy) / sequence_length}
+    return {"fst": fst, "pi_a": pi_a, "pi_b": pi_b, "pi_xy": pi_xy, "dxy": dxy, "da": dxy - pi_xy}

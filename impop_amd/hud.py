@@ -6,6 +6,8 @@ from __future__ import annotations
 
 import sys
 
+import numpy as np
+
 from .hfst import _flags
 from .popnames import read_subset_file  # noqa: F401  (hud.py:55-62 reads its lists the same way)
 from .runtime import default_context
@@ -21,17 +23,20 @@ def calculate_fst(similarities, pop_a, pop_b, sequence_length=None, round_digits
 
 
 def _log_text(method, threshold, round_digits, size_a, size_b, v, cnt, sequence_length) -> str:
-    """The `<basename>_fst.log` text of hud.py:194-289 for the values v = (fst, pi_a, pi_b, pi_xy, dxy) and the
-    kernel's counters; a log file is part of what the drop-in replaces, so the wording is the reference's."""
+    """The `<basename>_fst.log` text of hud.py:194-289 — and, with method=None, of h-fst.py:187-231, which is the
+    same text without the method lines — for the values v = (fst, pi_a, pi_b, pi_xy, dxy) and the kernel's
+    counters; a log file is part of what the drop-in replaces, so the wording is the reference's."""
     fst, pi_a, pi_b, pi_xy, dxy = v
     grouped = method == "grouped"
-    out = ["FST Calculation", "=" * 50, f"Population A: {size_a} sequences", f"Population B: {size_b} sequences",
-           f"Method: {method}"]
+    out = ["FST Calculation", "=" * 50, f"Population A: {size_a} sequences", f"Population B: {size_b} sequences"]
+    if method is not None:
+        out.append(f"Method: {method}")
     if grouped:
         out.append(f"Grouping threshold: {threshold}")
     if round_digits is not None:
         out.append(f"Rounding similarities to {round_digits} decimal places")
-    out += ["", f"Within-population diversity (π) using {method} method:"]
+    out += ["", f"Within-population diversity (π) using {method} method:" if method is not None
+            else "Within-population diversity (π):"]
     for tag, pi, size, k in (("A", pi_a, size_a, 0), ("B", pi_b, size_b, 2)):
         if grouped:
             out.append(f"  π{tag} = {pi:.6f} ({cnt[k]} groups from {size} sequences, {cnt[k + 1]} missing pairs)")
@@ -67,7 +72,14 @@ def calculate_fst_dense(names, dense, pop_a, pop_b, sequence_length=None, round_
         raise KeyError(f"{len(strangers)} population members absent from the identity table's name list")
     fa, fb = _flags(names, pop_a), _flags(names, pop_b)
     if method == "grouped":
-        out, cnt = ctx.fst_grouped_from_identity(dense, fa, fb, threshold, None, round_digits)
+        # hud.py:67-71 seeds its greedy groups with set.pop() from `set(sequences)`: hand the kernel that
+        # iteration order for each population (same expression, same object, same interpreter: same order)
+        at = {nm: i for i, nm in enumerate(names)}
+        rank = np.zeros(len(names), dtype=np.uint32)
+        for pop in (pop_a, pop_b):
+            for k, nm in enumerate(set(pop)):
+                rank[at[nm]] = k
+        out, cnt = ctx.fst_grouped_from_identity(dense, fa, fb, threshold, None, round_digits, seed_rank=rank)
     else:
         out, cnt = ctx.fst_from_identity(dense, fa, fb, None, round_digits)
     fst, pi_a, pi_b, pi_xy, dxy = (float(x) for x in out[:5])

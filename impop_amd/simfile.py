@@ -117,9 +117,11 @@ def densify(similarity_dict, names: Sequence[str]) -> np.ndarray:
     return out
 
 
-def read_dense(filename, flavor: str = "pica2"):
+def read_dense(filename, flavor: str = "pica2", with_elements: bool = False):
     """Fast ingest used by the drop-in CLIs: (sorted names, dense [n,n] identity with NaN for absent
-    pairs, number of data rows).  Clean tab-separated files go through the native parser in
+    pairs, number of data rows[, elements]).  `elements` (with_elements=True) is the set of names built the
+    way the reference's reader builds it — one add() per distinct name in file order (pica2.py:45-46) — so
+    that its iteration order, which seeds pica2's greedy grouping, is the reference's.  Clean tab-separated files go through the native parser in
     libimpop_hip.so (impop_sim_parse); any file shape it declines (quotes, short rows, unusual
     number syntax, missing columns) — and every error path — goes through the reference-faithful
     Python readers above, so messages and exit codes are the reference's."""
@@ -140,7 +142,14 @@ def read_dense(filename, flavor: str = "pica2"):
                 dense = np.empty((n.value, n.value))
                 _lib.check(lib.impop_sim_dense(h, dense.ctypes.data_as(C.POINTER(C.c_double))))
                 if n.value or rows.value:
-                    return names, dense, int(rows.value)
+                    if not with_elements:
+                        return names, dense, int(rows.value)
+                    seen = np.zeros(max(n.value, 1), dtype=np.uint32)
+                    _lib.check(lib.impop_sim_first_seen(h, seen.ctypes.data_as(C.POINTER(C.c_uint32))))
+                    elements = set()
+                    for k in seen[: n.value]:
+                        elements.add(names[int(k)])
+                    return names, dense, int(rows.value), elements
         finally:
             lib.impop_sim_free(h)
     # fall back: exact reference behaviour (including its messages / sys.exit) for everything else
@@ -150,4 +159,6 @@ def read_dense(filename, flavor: str = "pica2"):
         d, elements = read_similarity_file_hfst(filename)
         pair_count = len(d)
     names = sorted(elements)
+    if with_elements:
+        return names, densify(d, names), pair_count, elements
     return names, densify(d, names), pair_count

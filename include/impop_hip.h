@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define IMPOP_ABI_VERSION 1
+#define IMPOP_ABI_VERSION 2
 
 typedef enum impop_status {
     IMPOP_OK = 0,
@@ -53,8 +53,10 @@ typedef struct impop_scan_plan impop_scan_plan;
 int impop_version(void);                 /* IMPOP_ABI_VERSION */
 const char *impop_last_error(void);      /* thread-local, never NULL */
 int impop_device_count(int *count);
-/* stream: an existing hipStream_t (e.g. torch's current stream) or NULL to
- * create a private non-blocking stream. */
+/* stream: an existing hipStream_t created by the caller (its ordering is then the caller's: collectives
+ * and copies issued on it see the scans), or NULL to create a private non-blocking stream.  NULL is also
+ * HIP's legacy null stream — it cannot be adopted; a caller that works on the null stream (torch's default
+ * stream reports handle 0) must create an explicit stream and pass that. */
 int impop_ctx_create(int device, void *stream, impop_ctx **out);
 int impop_ctx_destroy(impop_ctx *ctx);
 int impop_ctx_synchronize(impop_ctx *ctx);
@@ -264,10 +266,28 @@ int impop_pairwise_scan(impop_ctx *ctx, const impop_matrix *m, const impop_windo
 
 /* pica2.analyze_similarity_matrix (pica2.py:60-169).  seq_len 0 = None.
  * group_of (nullable, n entries): 0-based index of each element's group in the
- * reference's sorted group order.  Seed of each greedy group = smallest
- * remaining index (the reference's set.pop() order is unspecified, pica2.py:100). */
+ * reference's sorted group order (pica2.py:110-112).
+ * seed_rank (nullable, n entries, distinct values): the order in which the greedy grouping of
+ * pica2.py:96-110 takes its seeds.  The reference takes them with set.pop() from `remaining =
+ * set(elements)`, which walks the set's hash table from slot 0 without ever rehashing, so its seed order is
+ * the iteration order of `set(elements)` restricted to what is left; a caller in the same interpreter passes
+ * seed_rank[i] = position of element i in list(set(elements)) and gets the reference's groups for
+ * non-transitive tables too (impop_amd/pica2.py does).  NULL = seed with the smallest remaining index
+ * (lexicographically smallest name): deterministic, and one of the orders the reference can take.
+ * detail (nullable): the two intermediate values pica2's log prints (pica2.py:158-159). */
+typedef struct impop_pica2_detail {
+    double sum_2pairs;          /* sum(2 * pair for pair in group_pairs) */
+    uint64_t n_pairs_with_data; /* len(group_pairs) */
+} impop_pica2_detail;
 int impop_pi_from_identity(impop_ctx *ctx, const double *ident, uint32_t n, double threshold, int round_digits,
-                           uint64_t seq_len, double *pi, double *pi_site, uint32_t *group_of, uint32_t *n_groups);
+                           uint64_t seq_len, const uint32_t *seed_rank, double *pi, double *pi_site, uint32_t *group_of,
+                           uint32_t *n_groups, impop_pica2_detail *detail);
+/* The "Step 2" table of pica2's log (pica2.py:125-145) for given groups: rep[g] = index of group g's first
+ * member, group_size[g]; for the pairs g < h in row-major order sims_out = identity of the two
+ * representatives (rounded like the analysis; NaN = pair absent) and values_out = (1 - sim) * f_g * f_h.
+ * Both arrays hold n_groups*(n_groups-1)/2 doubles. */
+int impop_pica2_pair_terms(impop_ctx *ctx, const double *ident, uint32_t n, int round_digits, const uint32_t *rep,
+                           const uint32_t *group_size, uint32_t n_groups, double *sims_out, double *values_out);
 
 /* h-fst.calculate_fst (h-fst.py:173-249).  in_a / in_b: n membership flags.
  * out[6] = fst, pi_a, pi_b, pi_xy, dxy, da.
@@ -279,10 +299,13 @@ int impop_fst_from_identity(impop_ctx *ctx, const double *ident, uint32_t n, con
 /* scripts/hudson/hud.py calculate_fst(method='grouped') (hud.py:64-128, 173-300): greedy groups
  * inside each population at `threshold`, frequency-weighted group-pair sums; the similarity of two
  * groups is the first pair (members in sorted order) present in the table.  out[6] as above;
- * counts[6] = groups_a, missing_a, groups_b, missing_b, group pairs between, missing between. */
+ * counts[6] = groups_a, missing_a, groups_b, missing_b, group pairs between, missing between.
+ * seed_rank (nullable, n entries): seed order of hud.py:64-86's set.pop() inside each population, as for
+ * impop_pi_from_identity — values must be distinct among the members of A and among those of B (position
+ * in list(set(pop_a)) / list(set(pop_b))); entries of non-members are ignored. */
 int impop_fst_grouped_from_identity(impop_ctx *ctx, const double *ident, uint32_t n, const uint8_t *in_a,
                                     const uint8_t *in_b, double threshold, uint64_t seq_len, int round_digits,
-                                    double *out, uint64_t *counts);
+                                    const uint32_t *seed_rank, double *out, uint64_t *counts);
 
 /* tj_d.tajimas_d (tj_d.py:47-69) for `count` (n, S, pi) triples.  comps
  * (nullable): count x 10 doubles a1,a2,b1,b2,c1,c2,e1,e2,numerator,denominator.
@@ -311,6 +334,10 @@ int impop_sim_parse(const char *path, int flavor, impop_sim **out);
 int impop_sim_info(const impop_sim *s, uint32_t *n_names, uint64_t *n_rows, uint64_t *names_bytes,
                    int64_t *bad_line, uint64_t *n_bad);
 int impop_sim_names(const impop_sim *s, char *buf);          /* NUL-separated, sorted */
+/* first_seen_out[k] (n_names entries) = sorted rank of the k-th distinct name in file order (group.a before
+ * group.b within a row): the insertion order of the reference reader's `elements` set (pica2.py:45-46),
+ * from which the caller rebuilds that set and hence pica2's seed order (see impop_pi_from_identity). */
+int impop_sim_first_seen(const impop_sim *s, uint32_t *first_seen_out);
 int impop_sim_bad_text(const impop_sim *s, char *buf, size_t buflen);
 int impop_sim_dense(const impop_sim *s, double *out);        /* n x n, sorted-name order, NaN = absent */
 int impop_sim_free(impop_sim *s);

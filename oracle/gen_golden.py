@@ -109,7 +109,116 @@ def founder_matrix(rng, n, W, n_founder, p_founder, p_private):
     return m, who
 
 
+# Every child process runs under a FIXED hash seed: where the reference's result depends on set order (pica2 /
+# hud grouping on non-transitive tables) the fixture records which seed produced it, and a regeneration is
+# byte-identical whatever seed this parent process happens to run under.
+CHILD_ENV = dict(os.environ, PYTHONHASHSEED="0")
+
+
+def seeded_child(spec_path):
+    """Runs in a child under PYTHONHASHSEED=k: the REAL pica2.analyze_similarity_matrix / hud.calculate_fst on a
+    non-transitive table, plus the set iteration orders they seeded their greedy groups from."""
+    spec = json.load(open(spec_path))
+    sc = spec["scripts"]
+    pica2 = load("ref_pica2", os.path.join(sc, "pica2.py"))
+    hud = load("ref_hud", os.path.join(sc, "hudson", "hud.py"))
+    names = spec["names"]
+    sim = [[float.fromhex(v) for v in row] for row in spec["sim"]]
+    n = len(names)
+    d = {(names[i], names[j]): sim[i][j] for i in range(n) for j in range(i, n)}
+    elements = set()
+    for k in spec["insert_order"]:  # the order a reader met the names in
+        elements.add(names[k])
+    out = {"hashseed": os.environ.get("PYTHONHASHSEED"), "order": list(set(elements)), "pica2": [], "hud": []}
+    for thr, rd in spec["pica2_cases"]:
+        log = io.StringIO()
+        pi, ps = pica2.analyze_similarity_matrix(dict(d), elements, len(d), thr, spec["L"], log, rd)
+        groups = [ln.strip() for ln in log.getvalue().splitlines() if ln.startswith("  G") and "(size:" in ln]
+        out["pica2"].append({"threshold": float(thr).hex(), "round": rd, "pi": hx(pi), "pi_site": hx(ps), "n_groups": len(groups)})
+    A = set()
+    for k in spec["insert_order"]:
+        if spec["in_a"][k]:
+            A.add(names[k])
+    B = set()
+    for k in spec["insert_order"]:
+        if spec["in_b"][k]:
+            B.add(names[k])
+    out["order_a"], out["order_b"] = list(set(A)), list(set(B))
+    for thr, rd in spec["hud_cases"]:
+        r = hud.calculate_fst(d, A, B, spec["L"], rd, None, "grouped", thr)
+        out["hud"].append({"threshold": float(thr).hex(), "round": rd, "out": {k: hx(v) for k, v in r.items()}})
+    print(json.dumps(out))
+
+
+def seeded_fixture(sc, out_dir, meta):
+    """tests/golden/pica2_seeded.json: tables where "> threshold" is NOT transitive (the normal case at the
+    pipeline defaults -t 0.999 -r 5).  The reference's greedy grouping then depends on set iteration order;
+    for PYTHONHASHSEED = 0..K-1 record the order it iterated and the value it returned (library level), and
+    the stdout + log of the real pica2.py CLI on the same table written as a .sim file."""
+    rng = np.random.default_rng(20251102)
+    tables = []
+    def chain(n, step):  # SURVEY §8a-a3's example: identity 1 - step*|i-j|
+        return np.array([[1.0 - step * abs(i - j) for j in range(n)] for i in range(n)])
+    m, _ = founder_matrix(rng, 36, 900, 5, 0.01, 0.002)
+    I = np_counts(m)
+    specs = [("chain5", chain(5, 0.0004), 40, [(0.999, None)], [(0.999, None)]),
+             ("chain12", chain(12, 0.0004), 10, [(0.999, None), (0.9985, 5)], [(0.999, None)]),
+             ("chain31", chain(31, 0.00035), 10, [(0.999, None), (0.999, 3), (0.9975, None)], [(0.999, None), (0.998, 4)]),
+             ("founders36_match", np_identity(I, 900, "match"), 10, None, None),
+             ("founders36_dice", np_identity(I, 900, "dice"), 10, None, None)]
+    for name, sim, n_seeds, pcases, hcases in specs:
+        n = sim.shape[0]
+        names = names_for(n, "chr7", 1000, 51000)
+        off = sim[~np.eye(n, dtype=bool)]
+        if pcases is None:
+            q = [float(np.quantile(off, x)) for x in (0.5, 0.8)]
+            pcases = [(q[0], None), (q[1], None), (q[1], 3)]
+            hcases = [(q[0], None), (q[1], 4)]
+        pcases = [c for c in pcases if not is_equivalence(sim, c[0], c[1])]
+        assert pcases, name
+        ins = rng.permutation(n).tolist()
+        in_a = [1 if (i % 3) != 2 and i < (2 * n) // 3 else 0 for i in range(n)]
+        in_b = [1 if not in_a[i] else 0 for i in range(n)]
+        spec = {"scripts": sc, "names": names, "sim": [[hx(v) for v in row] for row in sim], "insert_order": ins,
+                "pica2_cases": pcases, "hud_cases": hcases, "L": 50000, "in_a": in_a, "in_b": in_b}
+        runs = []
+        with tempfile.TemporaryDirectory() as td:
+            sp = os.path.join(td, "spec.json")
+            json.dump(spec, open(sp, "w"))
+            simfile = os.path.join(td, f"{name}.sim")
+            with open(simfile, "w") as f:  # rows in a shuffled order: the reader's insertion order is not the sorted one
+                f.write("group.a\tgroup.b\testimated.identity\n")
+                pairs = [(i, j) for i in range(n) for j in range(i, n)]
+                for k in rng.permutation(len(pairs)):
+                    i, j = pairs[k]
+                    f.write(f"{names[i]}\t{names[j]}\t{float(sim[i, j])!r}\n")
+            sim_text = open(simfile).read()
+            for seed in range(n_seeds):
+                env = dict(os.environ, PYTHONHASHSEED=str(seed))
+                r = subprocess.run([sys.executable, "-B", os.path.abspath(__file__), "--seeded-child", sp], capture_output=True,
+                                   text=True, env=env, check=True)
+                rec = json.loads(r.stdout)
+                rec["cli"] = []
+                for thr, rd in pcases[:2]:
+                    argv = [os.path.join(sc, "pica2.py"), simfile, "-t", repr(float(thr)), "-l", "50000", "-d", td] + (["-r", str(rd)] if rd is not None else [])
+                    c = subprocess.run([sys.executable, "-B"] + argv, capture_output=True, text=True, env=env, cwd=td)
+                    logp = os.path.join(td, f"{name}.log")
+                    rec["cli"].append({"t": repr(float(thr)), "r": rd, "l": 50000, "stdout": c.stdout, "rc": c.returncode,
+                                       "log": open(logp).read().replace(td, "<TMP>")})
+                    os.remove(logp)
+                runs.append(rec)
+        tables.append({"name": name, "n": n, "names": names, "sim": spec["sim"], "insert_order": ins, "L": 50000,
+                       "in_a": in_a, "in_b": in_b, "sim_text": sim_text, "runs": runs})
+    json.dump({"meta": dict(meta, PYTHONHASHSEED="per run"), "tables": tables}, open(os.path.join(out_dir, "pica2_seeded.json"), "w"), indent=1)
+
+
 def main():
+    if len(sys.argv) == 3 and sys.argv[1] == "--seeded-child":
+        return seeded_child(sys.argv[2])
+    if os.environ.get("PYTHONHASHSEED") != "0":
+        # h-fst / hud sum over Python sets, so even their deterministic results move in the last bits with the
+        # string hash seed: the whole generator runs under seed 0 and a regeneration is byte-identical
+        return sys.exit(subprocess.run([sys.executable, "-B", os.path.abspath(__file__)] + sys.argv[1:], env=CHILD_ENV).returncode)
     ap = argparse.ArgumentParser()
     ap.add_argument("--ref", default="/root/reference")
     ap.add_argument("--out", default=os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden"))
@@ -121,7 +230,7 @@ def main():
     af = load("ref_af", os.path.join(sc, "af.py"))
     hud = load("ref_hud", os.path.join(sc, "hudson", "hud.py"))
     os.makedirs(args.out, exist_ok=True)
-    meta = {"python": sys.version.split()[0], "PYTHONHASHSEED": os.environ.get("PYTHONHASHSEED", "random"),
+    meta = {"python": sys.version.split()[0], "PYTHONHASHSEED": "0 (the generator re-executes itself under it)",
             "generator": "oracle/gen_golden.py", "reference": "pangenome/impop @ /root/reference (2025-10-31 snapshot)"}
 
     # ------------------------------------------------------------------ tajima
@@ -184,14 +293,19 @@ def main():
         pa, pb = os.path.join(td, "pop_A.txt"), os.path.join(td, "pop_B.txt")
         open(pa, "w").write("seq1_popA\nseq2_popA\nseq3_popA\n")
         open(pb, "w").write("seq4_popB\nseq5_popB\nseq6_popB\n")
-        def run(argv):
-            r = subprocess.run([sys.executable, "-B"] + argv, capture_output=True, text=True, cwd=td)
-            return {"argv": [os.path.basename(a) if a.startswith(td) or a.startswith(sc) else a for a in argv],
-                    "stdout": r.stdout, "rc": r.returncode}
+        def run(argv, log=None):
+            r = subprocess.run([sys.executable, "-B"] + argv, capture_output=True, text=True, cwd=td, env=CHILD_ENV)
+            out = {"argv": ["<TMP>" if a == td else os.path.basename(a) if a.startswith(td) or a.startswith(sc) else a for a in argv],
+                   "stdout": r.stdout.replace(td, "<TMP>"), "rc": r.returncode}
+            if log and os.path.exists(os.path.join(td, log)):  # the script's log file, temp dir masked
+                out["log"] = open(os.path.join(td, log)).read().replace(td, "<TMP>")
+                os.remove(os.path.join(td, log))
+            return out
         six["cli"] = {
-            "pica2": [run([os.path.join(sc, "pica2.py"), p, "-t", t, "-l", "1000", "-d", td] + (["-r", r] if r else []))
+            "pica2": [run([os.path.join(sc, "pica2.py"), p, "-t", t, "-l", "1000", "-d", td] + (["-r", r] if r else []),
+                          log="example_similarities.log")
                       for t, r in (("0.999", "5"), ("1.0", None), ("0.9996", "4"), ("0.99", None))]
-                     + [run([os.path.join(sc, "pica2.py"), p, "-t", "0.999", "-d", td])],
+                     + [run([os.path.join(sc, "pica2.py"), p, "-t", "0.999", "-d", td], log="example_similarities.log")],
             # NB: bare names become the prefix 'seq1_popA#' (h-fst.py:57-61) and match nothing -> rc 1
             "hfst": [run([os.path.join(sc, "h-fst.py"), p, "-a", pa, "-b", pb, "-l", "1000000", "-d", td])],
             "tj_d": [run([os.path.join(sc, "tj_d.py"), "-n", "446", "-p", "0.59146123", "-S", "20"]),
@@ -267,9 +381,9 @@ def main():
                 r = hfst.calculate_fst(d, set(A), set(B), Lx, rd)
                 out["hfst"].append({"L": Lx, "round": rd, "out": {k: hx(v) for k, v in r.items()}})
             # overlapping populations (h-fst.py:181-185)
-            Bov = set(B) | set(list(A)[:2])
+            Bov = set(B) | set(sorted(A)[:2])  # sorted(): the fixture must not depend on the hash seed
             r = hfst.calculate_fst(d, set(A), set(Bov), L, None)
-            out["hfst_overlap"] = {"extra_in_b": sorted(list(A)[:2]), "L": L, "out": {k: hx(v) for k, v in r.items()}}
+            out["hfst_overlap"] = {"extra_in_b": sorted(A)[:2], "L": L, "out": {k: hx(v) for k, v in r.items()}}
             # hud.py grouped method: only where '> thr' is an equivalence relation inside BOTH populations
             out["hud_grouped"] = []
             for thr in (0.999, 0.99, float(np.median(offdiag)), 1.0):
@@ -309,16 +423,21 @@ def main():
         pa, pb = os.path.join(td, "popA.txt"), os.path.join(td, "popB.txt")
         open(pa, "w").write("# population A\nS0000_hap1_hprc_r2_v1.0.1\nS0001\n\n")
         open(pb, "w").write("S0002_mat_hprc_r2_v1.0.1\nS0003#2\nS0002_pat\nNOPE_hap1\n")
-        def run2(argv):
-            r = subprocess.run([sys.executable, "-B"] + argv, capture_output=True, text=True, cwd=td)
-            return {"argv": [os.path.basename(a) if a.startswith(td) or a.startswith(sc) else a for a in argv],
-                    "stdout": r.stdout, "stderr": r.stderr.replace(td, "<TMP>"), "rc": r.returncode}
+        def run2(argv, log=None):
+            r = subprocess.run([sys.executable, "-B"] + argv, capture_output=True, text=True, cwd=td, env=CHILD_ENV)
+            out = {"argv": ["<TMP>" if a == td else os.path.basename(a) if a.startswith(td) or a.startswith(sc) else a for a in argv],
+                   "stdout": r.stdout.replace(td, "<TMP>"), "stderr": r.stderr.replace(td, "<TMP>"), "rc": r.returncode}
+            if log and os.path.exists(os.path.join(td, log)):
+                out["log"] = open(os.path.join(td, log)).read().replace(td, "<TMP>")
+                os.remove(os.path.join(td, log))
+            return out
         cli = {"sim_text": open(p).read(), "popA": open(pa).read(), "popB": open(pb).read(),
-               "pica2": [run2([os.path.join(sc, "pica2.py"), p, "-t", t, "-l", "1000", "-d", td] + (["-r", r] if r else []))
+               "pica2": [run2([os.path.join(sc, "pica2.py"), p, "-t", t, "-l", "1000", "-d", td] + (["-r", r] if r else []),
+                              log="win8.log")
                          for t, r in (("1.0", None), ("0.999", "5"), ("0.99", None))],
-               "hfst": [run2([os.path.join(sc, "h-fst.py"), p, "-a", pa, "-b", pb, "-l", "1000", "-d", td]),
-                        run2([os.path.join(sc, "h-fst.py"), p, "-a", pa, "-b", pb, "-d", td, "-r", "4"]),
-                        run2([os.path.join(sc, "h-fst.py"), p, "-a", pa, "-b", pa, "-d", td])],
+               "hfst": [run2([os.path.join(sc, "h-fst.py"), p, "-a", pa, "-b", pb, "-l", "1000", "-d", td], log="win8_fst.log"),
+                        run2([os.path.join(sc, "h-fst.py"), p, "-a", pa, "-b", pb, "-d", td, "-r", "4"], log="win8_fst.log"),
+                        run2([os.path.join(sc, "h-fst.py"), p, "-a", pa, "-b", pa, "-d", td], log="win8_fst.log")],
                "af": [run2([os.path.join(sc, "af.py"), "--input", p, "--threshold", "1.0"]),
                       run2([os.path.join(sc, "af.py"), "--input", p, "--threshold", "0.99"])],
                "errors": [run2([os.path.join(sc, "pica2.py"), os.path.join(td, "nope.sim"), "-d", td]),
@@ -400,6 +519,7 @@ def main():
     pi1 = pica2.analyze_similarity_matrix({("x", "x"): 1.0}, {"x"}, 1, 1.0, 100, io.StringIO(), None)
     rag["degenerate"] = {"empty": [hx(v) for v in pi0], "single": [hx(v) for v in pi1]}
     json.dump({"meta": meta, **rag}, open(os.path.join(args.out, "ragged.json"), "w"), indent=1)
+    seeded_fixture(sc, args.out, meta)
     print("wrote goldens to", os.path.abspath(args.out))
 
 

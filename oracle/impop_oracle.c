@@ -84,6 +84,60 @@ ORACLE_API int oracle_tajimas_d(int64_t n, double S, double pi, double *D, doubl
 }
 
 /* ------------------------------------------------------------------------- */
+/* Greedy grouping of pica2.py:94-112 and hud.py:64-86, restated literally:    */
+/*   remaining = set(elements); while remaining: current = remaining.pop();    */
+/*   every `other` still remaining with sim(current, other) > threshold joins; */
+/*   groups.append(sorted(group)); finally groups.sort().                      */
+/* set.pop() walks the hash table from slot 0 and removals never rehash, so    */
+/* the seeds come in the iteration order of `set(elements)` restricted to what */
+/* is left.  seed_rank (nullable): seed_rank[idx[k]] = position of member k in */
+/* that order (distinct among the members); NULL = index order (the engine's   */
+/* documented default: smallest remaining name).  idx (nullable) = members.    */
+/* grp[k] = group of member k, groups numbered as after groups.sort() (by      */
+/* their smallest member); rep[g] (nullable) = member position of groups[g][0] */
+static uint32_t greedy_groups(const double *sim, uint32_t n, const uint32_t *idx, uint32_t m, double thr, int rd,
+                              const uint32_t *seed_rank, uint32_t *grp, uint32_t *rep) {
+    const uint32_t NONE = 0xFFFFFFFFu;
+    uint32_t *order = (uint32_t *)malloc((size_t)(m ? m : 1) * sizeof(uint32_t));
+    for (uint32_t k = 0; k < m; ++k) order[k] = k;
+    if (seed_rank) /* insertion sort by rank: test sizes are small */
+        for (uint32_t k = 1; k < m; ++k) {
+            uint32_t v = order[k], j = k;
+            while (j > 0 && seed_rank[idx ? idx[order[j - 1]] : order[j - 1]] > seed_rank[idx ? idx[v] : v]) { order[j] = order[j - 1]; --j; }
+            order[j] = v;
+        }
+    uint32_t *raw = (uint32_t *)malloc((size_t)(m ? m : 1) * sizeof(uint32_t));
+    uint32_t *gmin = (uint32_t *)malloc((size_t)(m ? m : 1) * sizeof(uint32_t));
+    for (uint32_t k = 0; k < m; ++k) raw[k] = NONE;
+    uint32_t G = 0;
+    for (uint32_t q = 0; q < m; ++q) {
+        const uint32_t s = order[q];            /* remaining.pop() */
+        if (raw[s] != NONE) continue;
+        raw[s] = G; gmin[G] = s;
+        for (uint32_t o = 0; o < m; ++o) {      /* for other in list(remaining) */
+            if (raw[o] != NONE) continue;
+            uint32_t a = idx ? idx[s] : s, b = idx ? idx[o] : o;
+            double v = a <= b ? sim[(size_t)a * n + b] : sim[(size_t)b * n + a];
+            if (isnan(v)) continue;             /* pair absent: get() is None / key not in similarities */
+            if (rd >= 0) v = oracle_py_round(v, rd);
+            if (v > thr) { raw[o] = G; if (o < gmin[G]) gmin[G] = o; } /* strict > (pica2.py:106, hud.py:80) */
+        }
+        ++G;
+    }
+    /* sorted(group) puts the smallest member first; groups.sort() orders the groups by it */
+    uint32_t *newid = (uint32_t *)malloc((size_t)(G ? G : 1) * sizeof(uint32_t));
+    for (uint32_t g = 0; g < G; ++g) {
+        uint32_t r = 0;
+        for (uint32_t h = 0; h < G; ++h) r += gmin[h] < gmin[g];
+        newid[g] = r;
+        if (rep) rep[r] = gmin[g];
+    }
+    for (uint32_t k = 0; k < m; ++k) grp[k] = newid[raw[k]];
+    free(order); free(raw); free(gmin); free(newid);
+    return G;
+}
+
+/* ------------------------------------------------------------------------- */
 /* pica2.py:60-169  analyze_similarity_matrix                                  */
 /* sim: dense n×n (symmetric; only (min,max) entry is consulted like the dict  */
 /* key at pica2.py:86); NaN = missing.  round_digits < 0 => None.              */
@@ -93,9 +147,9 @@ ORACLE_API int oracle_tajimas_d(int64_t n, double S, double pi, double *D, doubl
 /* seed order gives the same groups, so goldens use such inputs.               */
 /* group_of (nullable) receives the 0-based group index of every element,      */
 /* groups numbered in sorted order (pica2.py:110-112).                          */
-ORACLE_API int oracle_pica2(const double *sim, uint32_t n, double threshold, int round_digits,
-                            double seq_len, double *pi_out, double *pi_site_out,
-                            uint32_t *group_of, uint32_t *n_groups_out) {
+ORACLE_API int oracle_pica2_seeded(const double *sim, uint32_t n, double threshold, int round_digits,
+                                   double seq_len, const uint32_t *seed_rank, double *pi_out, double *pi_site_out,
+                                   uint32_t *group_of, uint32_t *n_groups_out) {
     double *S = NULL;
     if (round_digits >= 0) { /* pica2.py:81-83 */
         S = (double *)malloc((size_t)n * n * sizeof(double));
@@ -106,19 +160,9 @@ ORACLE_API int oracle_pica2(const double *sim, uint32_t n, double threshold, int
     uint32_t *grp = (uint32_t *)malloc((size_t)(n ? n : 1) * sizeof(uint32_t));
     uint32_t *rep = (uint32_t *)malloc((size_t)(n ? n : 1) * sizeof(uint32_t));
     uint32_t *gsz = (uint32_t *)calloc((size_t)(n ? n : 1), sizeof(uint32_t));
-    const uint32_t NONE = 0xFFFFFFFFu;
-    for (uint32_t i = 0; i < n; ++i) grp[i] = NONE;
-    uint32_t G = 0;
-    for (uint32_t seed = 0; seed < n; ++seed) { /* pica2.py:98-110 */
-        if (grp[seed] != NONE) continue;
-        grp[seed] = G; rep[G] = seed; gsz[G] = 1;
-        for (uint32_t o = seed + 1; o < n; ++o) {
-            if (grp[o] != NONE) continue;
-            double v = SIM(seed, o);
-            if (!isnan(v) && v > threshold) { grp[o] = G; gsz[G]++; } /* :106 strict > */
-        }
-        ++G;
-    }
+    /* pica2.py:94-112; values are already rounded in place (:81-83), hence rd = -1 here */
+    uint32_t G = greedy_groups(sim, n, NULL, n, threshold, -1, seed_rank, grp, rep);
+    for (uint32_t i = 0; i < n; ++i) gsz[grp[i]]++;
     double pi = 0.0, pi_site = 0.0;
     int have_pairs = 0;
     uint32_t total = n; /* pica2.py:121 */
@@ -147,6 +191,12 @@ ORACLE_API int oracle_pica2(const double *sim, uint32_t n, double threshold, int
     if (n_groups_out) *n_groups_out = G;
     free(grp); free(rep); free(gsz); free(S);
     return 0;
+}
+/* seed = smallest remaining index (lexicographically smallest name) */
+ORACLE_API int oracle_pica2(const double *sim, uint32_t n, double threshold, int round_digits,
+                            double seq_len, double *pi_out, double *pi_site_out,
+                            uint32_t *group_of, uint32_t *n_groups_out) {
+    return oracle_pica2_seeded(sim, n, threshold, round_digits, seq_len, NULL, pi_out, pi_site_out, group_of, n_groups_out);
 }
 
 /* ------------------------------------------------------------------------- */
@@ -454,25 +504,6 @@ ORACLE_API int oracle_to_sitemajor(const uint64_t *bits, uint64_t stride, uint32
 /* (seed = smallest remaining index here; the reference pops an arbitrary set  */
 /* member); get_group_similarity (:88-99): the first pair (member of g1 in     */
 /* sorted order x member of g2 in sorted order) present in the table.          */
-static uint32_t hud_groups(const double *sim, uint32_t n, const uint32_t *idx, uint32_t m, double thr, int rd, uint32_t *grp) {
-    const uint32_t NONE = 0xFFFFFFFFu;
-    for (uint32_t i = 0; i < m; ++i) grp[i] = NONE;
-    uint32_t G = 0;
-    for (uint32_t s = 0; s < m; ++s) {
-        if (grp[s] != NONE) continue;
-        grp[s] = G;
-        for (uint32_t o = s + 1; o < m; ++o) {
-            if (grp[o] != NONE) continue;
-            uint32_t a = idx[s], b = idx[o];
-            double v = a <= b ? sim[(size_t)a * n + b] : sim[(size_t)b * n + a];
-            if (isnan(v)) continue;                       /* :76 key in similarities */
-            if (rd >= 0) v = oracle_py_round(v, rd);      /* :78-79 */
-            if (v > thr) grp[o] = G;                      /* :80 */
-        }
-        ++G;
-    }
-    return G;
-}
 static double hud_first_found(const double *sim, uint32_t n, const uint32_t *ia, const uint32_t *ga, uint32_t ma, uint32_t g1,
                               const uint32_t *ib, const uint32_t *gb, uint32_t mb, uint32_t g2, int rd) {
     for (uint32_t i = 0; i < ma; ++i) { if (ga[i] != g1) continue;
@@ -485,8 +516,8 @@ static double hud_first_found(const double *sim, uint32_t n, const uint32_t *ia,
     return NAN;
 }
 static double hud_pi_grouped(const double *sim, uint32_t n, const uint32_t *idx, uint32_t m, double thr, int rd,
-                             uint32_t *grp, uint32_t *G_out, uint64_t *missing) {
-    uint32_t G = hud_groups(sim, n, idx, m, thr, rd, grp);
+                             const uint32_t *seed_rank, uint32_t *grp, uint32_t *G_out, uint64_t *missing) {
+    uint32_t G = greedy_groups(sim, n, idx, m, thr, rd, seed_rank, grp, NULL); /* hud.py:64-86 */
     *G_out = G; *missing = 0;
     if (m <= 1) return 0.0;                               /* :106-107 */
     uint32_t *sz = (uint32_t *)calloc(G ? G : 1, sizeof(uint32_t));
@@ -503,8 +534,8 @@ static double hud_pi_grouped(const double *sim, uint32_t n, const uint32_t *idx,
     return acc * (double)m / (double)(m - 1);             /* :127 */
 }
 /* out[6] = fst, pi_a, pi_b, pi_xy, dxy, da; counts[6] = groups_a, miss_a, groups_b, miss_b, group pairs, miss_between */
-ORACLE_API int oracle_hud_grouped(const double *sim, uint32_t n, const uint8_t *in_a, const uint8_t *in_b, double threshold,
-                                  int round_digits, double seq_len, double *out, uint64_t *counts) {
+ORACLE_API int oracle_hud_grouped_seeded(const double *sim, uint32_t n, const uint8_t *in_a, const uint8_t *in_b, double threshold,
+                                         int round_digits, double seq_len, const uint32_t *seed_rank, double *out, uint64_t *counts) {
     uint32_t *ia = (uint32_t *)malloc((n ? n : 1) * 4), *ib = (uint32_t *)malloc((n ? n : 1) * 4);
     uint32_t *ga = (uint32_t *)malloc((n ? n : 1) * 4), *gb = (uint32_t *)malloc((n ? n : 1) * 4);
     uint32_t ma = 0, mb = 0;
@@ -514,8 +545,8 @@ ORACLE_API int oracle_hud_grouped(const double *sim, uint32_t n, const uint8_t *
         if (in_b[i] && !ov) ib[mb++] = i;
     }
     uint32_t GA, GB; uint64_t missA, missB, missX = 0, pairsX = 0;
-    double pi_a = hud_pi_grouped(sim, n, ia, ma, threshold, round_digits, ga, &GA, &missA);
-    double pi_b = hud_pi_grouped(sim, n, ib, mb, threshold, round_digits, gb, &GB, &missB);
+    double pi_a = hud_pi_grouped(sim, n, ia, ma, threshold, round_digits, seed_rank, ga, &GA, &missA);
+    double pi_b = hud_pi_grouped(sim, n, ib, mb, threshold, round_digits, seed_rank, gb, &GB, &missB);
     double pi_xy = 0.5 * (pi_a + pi_b);
     uint32_t *sa = (uint32_t *)calloc(GA ? GA : 1, 4), *sb = (uint32_t *)calloc(GB ? GB : 1, 4);
     for (uint32_t i = 0; i < ma; ++i) sa[ga[i]]++;
@@ -535,6 +566,10 @@ ORACLE_API int oracle_hud_grouped(const double *sim, uint32_t n, const uint8_t *
     if (counts) { counts[0] = GA; counts[1] = missA; counts[2] = GB; counts[3] = missB; counts[4] = pairsX; counts[5] = missX; }
     free(ia); free(ib); free(ga); free(gb); free(sa); free(sb);
     return 0;
+}
+ORACLE_API int oracle_hud_grouped(const double *sim, uint32_t n, const uint8_t *in_a, const uint8_t *in_b, double threshold,
+                                  int round_digits, double seq_len, double *out, uint64_t *counts) {
+    return oracle_hud_grouped_seeded(sim, n, in_a, in_b, threshold, round_digits, seq_len, NULL, out, counts);
 }
 
 /* ---- EHH: calc_EHH of scripts/wip/ehhgfa.py:6-21 (and ehh2.py:76-89) ----------------------------

@@ -43,6 +43,8 @@ def lib():
         L.oracle_py_round.argtypes = [C.c_double, C.c_int]
         L.oracle_tajimas_d.argtypes = [C.c_int64, C.c_double, C.c_double, _f64p, _f64p]
         L.oracle_pica2.argtypes = [_f64p, C.c_uint32, C.c_double, C.c_int, C.c_double, _f64p, _f64p, _u32p, _u32p]
+        L.oracle_pica2_seeded.argtypes = [_f64p, C.c_uint32, C.c_double, C.c_int, C.c_double, _u32p, _f64p, _f64p, _u32p, _u32p]
+        L.oracle_hud_grouped_seeded.argtypes = [_f64p, C.c_uint32, _u8p, _u8p, C.c_double, C.c_int, C.c_double, _u32p, _f64p, _u64p]
         L.oracle_hfst.argtypes = [_f64p, C.c_uint32, _u8p, _u8p, C.c_double, C.c_int, _f64p, _u64p]
         L.oracle_hud_grouped.argtypes = [_f64p, C.c_uint32, _u8p, _u8p, C.c_double, C.c_int, C.c_double, _f64p, _u64p]
         L.oracle_ehh.argtypes = [_u64p, C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint64, _u8p, C.c_int, _f64p]
@@ -85,14 +87,17 @@ def _dense(sim):
     return a
 
 
-def pica2(sim, threshold=1.0, seq_len=None, round_digits=None):
+def pica2(sim, threshold=1.0, seq_len=None, round_digits=None, seed_rank=None):
+    """seed_rank[i] = position of element i in the reference's `set(elements)` iteration order; None = index order"""
     a = _dense(sim)
     n = a.shape[0]
     pi, ps = C.c_double(), C.c_double()
     grp = np.zeros(max(n, 1), dtype=np.uint32)
     G = C.c_uint32()
-    lib().oracle_pica2(_p(a, _f64p), n, float(threshold), -1 if round_digits is None else int(round_digits),
-                       float(seq_len or 0), C.byref(pi), C.byref(ps), _p(grp, _u32p), C.byref(G))
+    sr = None if seed_rank is None else np.ascontiguousarray(seed_rank, dtype=np.uint32)
+    lib().oracle_pica2_seeded(_p(a, _f64p), n, float(threshold), -1 if round_digits is None else int(round_digits),
+                              float(seq_len or 0), _p(sr, _u32p) if sr is not None else None, C.byref(pi), C.byref(ps),
+                              _p(grp, _u32p), C.byref(G))
     return pi.value, ps.value, grp[:n].copy(), G.value
 
 
@@ -109,15 +114,17 @@ def hfst(sim, in_a, in_b, seq_len=None, round_digits=None):
     return dict(zip(keys, out.tolist())), cnt
 
 
-def hud_grouped(sim, in_a, in_b, threshold=0.999, seq_len=None, round_digits=None):
+def hud_grouped(sim, in_a, in_b, threshold=0.999, seq_len=None, round_digits=None, seed_rank=None):
     a = _dense(sim)
     n = a.shape[0]
     fa = np.ascontiguousarray(in_a, dtype=np.uint8)
     fb = np.ascontiguousarray(in_b, dtype=np.uint8)
     out = np.zeros(6)
     cnt = np.zeros(6, dtype=np.uint64)
-    lib().oracle_hud_grouped(_p(a, _f64p), n, _p(fa, _u8p), _p(fb, _u8p), float(threshold),
-                             -1 if round_digits is None else int(round_digits), float(seq_len or 0), _p(out, _f64p), _p(cnt, _u64p))
+    sr = None if seed_rank is None else np.ascontiguousarray(seed_rank, dtype=np.uint32)
+    lib().oracle_hud_grouped_seeded(_p(a, _f64p), n, _p(fa, _u8p), _p(fb, _u8p), float(threshold),
+                                    -1 if round_digits is None else int(round_digits), float(seq_len or 0),
+                                    _p(sr, _u32p) if sr is not None else None, _p(out, _f64p), _p(cnt, _u64p))
     keys = ("fst", "pi_a", "pi_b", "pi_xy", "dxy", "da")
     return dict(zip(keys, out.tolist())), cnt
 

@@ -31,8 +31,9 @@ def main():
     opt = make_parser("Hudson Fst (direct or grouped) of two populations from a pairwise identity table.", FLAGS).parse_args()
     chatty = note if opt.verbose else (lambda text: None)
     chatty(f"Reading similarity file: {opt.similarity_file}")
-    names, dense, _ = read_dense(opt.similarity_file, "hfst")
-    known = set(names)
+    # `known` = the reader's name set with the reference's insertion order: the intersections below, and through
+    # them the seed order of the grouped method, then come out as in the reference
+    names, dense, _, known = read_dense(opt.similarity_file, "hfst", with_elements=True)
     chatty("Reading population files...")
     pops = {tag: read_subset_file(path) for tag, path in (("A", opt.pop_a), ("B", opt.pop_b))}
     for tag in ("A", "B"):
@@ -45,7 +46,7 @@ def main():
         if absent:
             note(f"Warning: {len(absent)} sequences from population {tag} not found in similarity file")
     for tag in ("A", "B"):
-        pops[tag] &= known
+        pops[tag] = pops[tag] & known  # hud.py:386-387
     if not pops["A"] or not pops["B"]:
         note("Error: No valid sequences found in one or both populations")
         sys.exit(1)

@@ -41,6 +41,18 @@ def read_bed(path, contig_filter=None):
     return rows
 
 
+def awk_line_count(list_file):
+    """SAMPLE_COUNT of run_tajd.sh:83: `awk 'NF && $1 !~ /^#/' list | wc -l` — lines with at least one field whose
+    first field does not start with '#'; a name listed twice counts twice."""
+    n = 0
+    with open(list_file) as f:
+        for line in f:
+            fields = line.split()
+            if fields and not fields[0].startswith("#"):
+                n += 1
+    return n
+
+
 def flags_for(list_file, names):
     raw = read_subset_file(list_file)
     members, missing = expand_population(raw, set(names))
@@ -134,7 +146,10 @@ def main():
     sample_count = mf.n_hap
     if args.sample_list:
         mask_p, raw = flags_for(args.sample_list, names)
-        sample_count = len(raw)  # run_tajd.sh:83: SAMPLE_COUNT = non-blank, non-# lines of the list
+        sample_count = awk_line_count(args.sample_list)  # run_tajd.sh:83
+        if args.format in ("tajd", "all") and sample_count < 2:
+            print(f"Error: Need at least two samples to compute Tajima's D (found {sample_count})", file=sys.stderr)  # :84-87
+            sys.exit(1)
     if args.subset:
         mask_p, _ = flags_for(args.subset, names)
     if args.pop_a and args.pop_b:
@@ -223,8 +238,19 @@ def main():
             print(f"{reg}\t{L}\t{thr_txt}\t{r_txt}\t{ta}\t{tb}\t{tc}\t{avg}\t{fst}", file=out)
     if fmt in ("tajd", "all"):
         print("REGION\tLENGTH\tSAMPLES\tSEGREGATING_SITES\tPI\tTAJIMAS_D", file=out)
-        for reg, (b, e, L), r in zip(regions, wins, res):
-            D = float(r["tajima_d"])
+        d_col = res["tajima_d"]
+        n_matched = int(mask_p.sum()) if mask_p is not None else mf.n_hap
+        if sample_count != n_matched and len(res):
+            # run_tajd.sh:180 hands tj_d.py `-n SAMPLE_COUNT`, the list's LINE count, whatever the number of
+            # haplotypes those lines select (a bare sample name selects two, an unknown name none, a repeated
+            # line counts twice).  The scan evaluated D with n = matched haplotypes: redo D (on the GPU,
+            # impop_tajimas_d) with the reference's n, pi through the same "%.8f" text (run_tajd.sh:174) and S.
+            print(f"Warning: sample list has {sample_count} lines but selects {n_matched} haplotypes; Tajima's D uses "
+                  f"n = {sample_count} like run_tajd.sh", file=sys.stderr)
+            pi_txt = np.array([float(f"{float(x):.8f}") for x in res["pi_site"]])
+            d_col = ctx.tajimas_d(np.full(len(res), sample_count, dtype=np.int64), res["s_all"].astype(np.float64), pi_txt)
+        for reg, (b, e, L), r, D in zip(regions, wins, res, d_col):
+            D = float(D)
             taj = "NA" if D != D else repr(D)  # run_tajd.sh:192-194
             print(f"{reg}\t{L}\t{sample_count}\t{int(r['s_all'])}\t{float(r['pi_site']):.8f}\t{taj}", file=out)
     if args.output or rank != 0:

@@ -18,7 +18,9 @@ FLAGS = (
 def main():
     opt = make_parser("Nucleotide diversity of one window from its pairwise identity table.", FLAGS).parse_args()
     log_name = log_path_for(opt.input_file, opt.log_dir)
-    names, dense, n_rows = read_dense(opt.input_file, "pica2")  # native ingest; the reference's messages on errors
+    # native ingest (the reference's messages on errors); `elements` = the reader's name set, rebuilt with the
+    # reference's insertion order so that the grouping takes its seeds in the reference's order
+    names, dense, n_rows, elements = read_dense(opt.input_file, "pica2", with_elements=True)
     head = ["Nucleotide Diversity Analysis Log", "=================================", f"Input file: {opt.input_file}",
             f"Threshold: {opt.threshold}"]
     if opt.sequence_length:
@@ -29,7 +31,7 @@ def main():
     with open(log_name, "w") as log:
         log.write("\n".join(head) + "\n")
         pi, per_site = analyze_dense(names, dense, n_rows, threshold=opt.threshold, sequence_length=opt.sequence_length,
-                                     log_file=log, round_digits=opt.round_digits)
+                                     log_file=log, round_digits=opt.round_digits, elements=elements)
         tail = ["", "=" * 50, "FINAL RESULTS:", f"pi = {pi:.6f}"]
         if per_site is not None:
             tail.append(f"pi per site = {per_site:.8f}")

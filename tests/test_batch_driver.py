@@ -53,9 +53,39 @@ def test_batch_driver_tables(tmp_path, oracle):
             assert abs(float(got) - w[key]) <= 1.0000001e-8, (key, got, w[key])
         t = lines[9 + k].split("\t")
         assert t[:5] == [reg, str(L), "12", str(w["s_all"]), f"{w['pi_site']:.8f}"]
-        # D is printed with repr(); n = 12 list lines (run_tajd.sh:83) => recompute through the oracle
-        D, _ = oracle.tajimas_d(n, float(w["s_all"]), oracle.py_round(w["pi_site"], 8))
+        # D is printed with repr(); run_tajd.sh:180 gives tj_d.py `-n SAMPLE_COUNT` = the 12 list LINES
+        # (run_tajd.sh:83), not the 24 haplotypes they select => recompute through the oracle with n = 12
+        D, _ = oracle.tajimas_d(12, float(w["s_all"]), oracle.py_round(w["pi_site"], 8))
         assert abs(float(t[5]) - D) <= 1e-9 * abs(D)
+    assert "sample list has 12 lines but selects 24 haplotypes" in r.stderr
+    # haplotype-level list with a repeated line, an unknown name, a comment and a blank: SAMPLES = awk's count (5)
+    (tmp_path / "hap.txt").write_text("# panel\nS000_hap1\nS001#2\n\nS001#2\nNOPE_hap1\n  S003_mat\n")
+    rh = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "impop_scan.py"), "--matrix", str(tmp_path / "m.npz"),
+                         "--bed", str(tmp_path / "w.bed"), "--format", "tajd", "-l", str(tmp_path / "hap.txt")], capture_output=True, text=True)
+    assert rh.returncode == 0, rh.stderr
+    lh = rh.stdout.strip().split("\n")
+    sel = np.array([1 if nm.startswith(("S000#1#", "S001#2#", "S003#1#")) else 0 for nm in names], np.uint8)
+    for k, (s0, s1, L, reg) in enumerate(wins):
+        w = oracle.window_allpairs(bits, n, s0, s1, oracle.pack_mask(sel), oracle.pack_mask(inA), oracle.pack_mask(inB), L)
+        t = lh[1 + k].split("\t")
+        assert t[:5] == [reg, str(L), "5", str(w["s_all"]), f"{w['pi_site']:.8f}"]
+        D, _ = oracle.tajimas_d(5, float(w["s_all"]), oracle.py_round(w["pi_site"], 8))
+        assert (t[5] == "NA" and D != D) or abs(float(t[5]) - D) <= 1e-9 * abs(D)
+    assert "sample list has 5 lines but selects 3 haplotypes" in rh.stderr
+    # a list whose line count equals the matched haplotypes takes the scan's own D, without a warning
+    (tmp_path / "hap3.txt").write_text("S000_hap1\nS001#2\nS003_mat\n")
+    r3h = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "impop_scan.py"), "--matrix", str(tmp_path / "m.npz"),
+                          "--bed", str(tmp_path / "w.bed"), "--format", "tajd", "-l", str(tmp_path / "hap3.txt")], capture_output=True, text=True)
+    assert r3h.returncode == 0 and "sample list has" not in r3h.stderr
+    for k, (s0, s1, L, reg) in enumerate(wins):
+        w = oracle.window_allpairs(bits, n, s0, s1, oracle.pack_mask(sel), oracle.pack_mask(inA), oracle.pack_mask(inB), L)
+        t = r3h.stdout.strip().split("\n")[1 + k].split("\t")
+        assert t[2] == "3" and ((t[5] == "NA" and w["tajima_d"] != w["tajima_d"]) or abs(float(t[5]) - w["tajima_d"]) <= 1e-9 * abs(w["tajima_d"]))
+    # fewer than two lines: run_tajd.sh:84-87
+    (tmp_path / "one.txt").write_text("S000_hap1\n")
+    r1 = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "impop_scan.py"), "--matrix", str(tmp_path / "m.npz"),
+                         "--bed", str(tmp_path / "w.bed"), "--format", "tajd", "-l", str(tmp_path / "one.txt")], capture_output=True, text=True)
+    assert r1.returncode == 1 and "Need at least two samples" in r1.stderr
     # --compact: the same tables from the matrix compacted to its variable sites
     rc = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "impop_scan.py"), "--matrix", str(tmp_path / "m.npz"),
                          "--bed", str(tmp_path / "w.bed"), "--format", "all", "-A", str(tmp_path / "A.txt"), "-B", str(tmp_path / "B.txt"),

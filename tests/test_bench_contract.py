@@ -14,7 +14,9 @@ from conftest import ROOT
 
 pytestmark = pytest.mark.gpu
 REQUIRED = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
-            "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline")
+            "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "ranks")
+RANK_KEYS = ("backend", "kernel_ms_avg_min", "kernel_ms_avg_max", "kernel_ms_avg_per_rank", "gather_exposed_ms_per_step_max",
+             "gather_issue_host_ms_per_step_max", "elapsed_s_min", "elapsed_s_max", "gathered_records_checked")
 
 
 def _last_json(text):
@@ -36,6 +38,25 @@ def test_bench_single_gpu_line():
     rf = d["roofline"]
     assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12
+    for k in RANK_KEYS:  # the fields a bad N-GPU number is diagnosed from are present at N = 1 too
+        assert k in d["ranks"], k
+    assert len(d["ranks"]["kernel_ms_avg_per_rank"]) == 1
+
+
+def test_bench_one_rank_rccl_gather():
+    """The RCCL path itself (communicator, all_gather_into_tensor on device buffers, stream ordering between the
+    scan and the collective) with the one rank a one-GPU box allows; bench.py asserts inside that the buffers
+    gathered by the first AND the timed steps equal the records the rank computed.  2000 windows = a scan of
+    about a millisecond, so an unordered gather would read a buffer that is still being written."""
+    env = dict(os.environ, IMPOP_BENCH_FORCE_DIST="1")
+    env.pop("MASTER_PORT", None)  # no launcher: bench.py must pick a free port itself, not a fixed one
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "6", "--warmup", "2", "--n-windows", "2000",
+                        "--no-cpu-baseline"], capture_output=True, text=True, cwd=ROOT, env=env, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = _last_json(r.stdout)
+    assert d["n_gpus"] == 1 and d["ranks"]["backend"] == "rccl" and d["ranks"]["gathered_records_checked"] is True
+    assert d["ranks"]["gather_bytes_per_rank"] == 2000 * 128
+    assert d["ranks"]["kernel_ms_avg_min"] > 0
 
 
 def test_bench_two_ranks_gloo_rehearsal():
@@ -44,9 +65,11 @@ def test_bench_two_ranks_gloo_rehearsal():
         port = s.getsockname()[1]
     env = dict(os.environ, IMPOP_BENCH_BACKEND="gloo")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-                        "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3",
-                        "--warmup", "1", "--n-windows", "96"], capture_output=True, text=True, cwd=ROOT, env=env, timeout=600)
+                        "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4",
+                        "--warmup", "1", "--n-windows", "1500"], capture_output=True, text=True, cwd=ROOT, env=env, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     d = _last_json(r.stdout)
     assert d["n_gpus"] == 2 and d["value"] > 0 and d["cpu_baseline"] is None
-    assert d["config"]["windows_per_gpu"] == 96
+    assert d["config"]["windows_per_gpu"] == 1500  # a scan of ~0.7 ms per rank: ordering bugs would show
+    assert d["ranks"]["backend"] == "gloo-rehearsal" and d["ranks"]["gathered_records_checked"] is True
+    assert len(d["ranks"]["kernel_ms_avg_per_rank"]) == 2

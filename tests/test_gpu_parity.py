@@ -871,3 +871,80 @@ def test_weighted_sites_equal_bp_expanded_matrix(ctx, oracle):
         bn.set_site_weights(None)  # weights removed: plain node-level scan again
         assert int(bn.scan([wn[0]])[0]["n_sites"]) == K
         bn.free(); be.free()
+
+
+def _seeded_cases():
+    g = load_golden("pica2_seeded.json")
+    for t in g["tables"]:
+        sim = np.array([[fh(v) for v in row] for row in t["sim"]])
+        at = {nm: i for i, nm in enumerate(t["names"])}
+        for run in t["runs"]:
+            rank = np.zeros(t["n"], dtype=np.uint32)
+            for k, nm in enumerate(run["order"]):
+                rank[at[nm]] = k
+            hud_rank = np.zeros(t["n"], dtype=np.uint32)
+            for order in (run["order_a"], run["order_b"]):
+                for k, nm in enumerate(order):
+                    hud_rank[at[nm]] = k
+            yield t, run, sim, rank, hud_rank
+
+
+def test_pica2_nontransitive_tables_reproduce_reference_seed_order(ctx, oracle):
+    """SURVEY §8a-a3 closed: on tables where "> threshold" is NOT transitive the reference's pi depends on the
+    iteration order of set(elements).  Given the order each captured process (PYTHONHASHSEED 0..9) iterated, the
+    GPU grouping returns THAT process's pi to 1e-9 and its group count; groups equal the oracle's."""
+    checked = 0
+    for t, run, sim, rank, _ in _seeded_cases():
+        for c in run["pica2"]:
+            thr = fh(c["threshold"])
+            pi, ps, grp, G, (sum2, npairs) = ctx.pi_from_identity(sim, thr, c["round"], t["L"], seed_rank=rank, detail=True)
+            assert rel_close(pi, fh(c["pi"]), REL) and rel_close(ps, fh(c["pi_site"]), REL), (t["name"], run["hashseed"], c, pi)
+            assert G == c["n_groups"]
+            _, _, ogrp, oG = oracle.pica2(sim, thr, t["L"], c["round"], seed_rank=rank)
+            assert oG == G and (ogrp == grp).all()
+            assert npairs == G * (G - 1) // 2 and rel_close(pi, t["n"] / (t["n"] - 1) * sum2, 1e-15)
+            checked += 1
+    assert checked >= 100
+    # a rank array with a repeated value is refused, not silently tie-broken
+    import impop_amd
+    with pytest.raises(impop_amd.ImpopError):
+        ctx.pi_from_identity(np.eye(3), 0.5, None, None, seed_rank=np.array([0, 1, 1], np.uint32))
+
+
+def test_pica2_default_rule_is_a_reference_outcome_and_mirror_uses_set_order(ctx):
+    """Without an order the engine seeds with the smallest remaining name: its pi must be one of the values the
+    reference produced under the 40 captured hash seeds (chain5).  And the function-level mirror, handed a set,
+    follows THIS interpreter's iteration order of it — checked against the engine run on that order."""
+    from impop_amd import pica2
+    g = load_golden("pica2_seeded.json")
+    t = next(x for x in g["tables"] if x["name"] == "chain5")
+    sim = np.array([[fh(v) for v in row] for row in t["sim"]])
+    c0 = t["runs"][0]["pica2"][0]
+    captured = {fh(r["pica2"][0]["pi"]) for r in t["runs"]}
+    pi, _, _, _ = ctx.pi_from_identity(sim, fh(c0["threshold"]), c0["round"], t["L"])
+    assert any(rel_close(pi, w, REL) for w in captured), (pi, captured)
+    for t in g["tables"]:
+        sim = np.array([[fh(v) for v in row] for row in t["sim"]])
+        names, n = t["names"], t["n"]
+        d = {(names[i], names[j]): float(sim[i, j]) for i in range(n) for j in range(i, n)}
+        elements = set()
+        for k in t["insert_order"]:
+            elements.add(names[k])
+        rank = pica2.seed_rank_of(elements, names)
+        assert sorted(rank.tolist()) == list(range(n))
+        for c in t["runs"][0]["pica2"]:
+            got = pica2.analyze_similarity_matrix(dict(d), elements, len(d), fh(c["threshold"]), t["L"], None, c["round"], ctx=ctx)
+            want = ctx.pi_from_identity(sim, fh(c["threshold"]), c["round"], t["L"], seed_rank=rank)
+            assert got[0] == want[0] and got[1] == want[1]
+
+
+def test_hud_grouped_nontransitive_tables_reproduce_reference_seed_order(ctx):
+    checked = 0
+    for t, run, sim, _, hud_rank in _seeded_cases():
+        inA, inB = np.array(t["in_a"], np.uint8), np.array(t["in_b"], np.uint8)
+        for c in run["hud"]:
+            out, _ = ctx.fst_grouped_from_identity(sim, inA, inB, fh(c["threshold"]), t["L"], c["round"], seed_rank=hud_rank)
+            for k, key in enumerate(("fst", "pi_a", "pi_b", "pi_xy", "dxy", "da")):
+                assert rel_close(float(out[k]), fh(c["out"][key]), REL, 1e-300), (t["name"], run["hashseed"], key)
+            checked += 1
+    assert checked >= 50

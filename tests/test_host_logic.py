@@ -31,7 +31,7 @@ def test_abi_exports_every_declared_symbol():
     exported = {l.split()[-1] for l in out.splitlines() if " T " in l}
     assert declared <= exported
     assert all(s.startswith("impop_") for s in exported if not s.startswith("_")), exported  # nothing else leaks
-    assert lib.impop_version() == 1
+    assert lib.impop_version() == _lib.ABI_VERSION == int(re.search(r"#define IMPOP_ABI_VERSION (\d+)", hdr).group(1))
 
 
 def test_no_cpu_fallback_without_gpu():

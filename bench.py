@@ -446,7 +446,7 @@ def main():
                        "parallelism": f"windows sharded over {world} GPU(s), one all_gather of records per step"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                         "kernel": ("scan_tiles_kernel<%d,false>" % ((n + 31) // 32)) if n <= 512 else "scan_tiles_generic_kernel", "kernel_ms_avg": avg_kern_s * 1e3,
+                         "kernel": ("scan_tiles_kernel<%d,false>" % ((n + 31) // 32)) if n <= 512 else "scan_tiles_anyn_kernel<false,false>", "kernel_ms_avg": avg_kern_s * 1e3,
                          "algorithmic_bytes_per_launch": algo_bytes, "layout_bytes_per_launch": plan.bytes_streamed,
                          "layout_GBps": plan.bytes_streamed / avg_kern_s / 1e9},
             "cpu_baseline": cpu,

@@ -7,7 +7,9 @@ There is no CPU fallback: without the built library and a gfx950 GPU every compu
 entry point raises ImpopError.
 """
 from ._lib import ImpopError, SO_PATH  # noqa: F401
-from .engine import (BitMatrix, Context, ScanPlan, STATS_DTYPE, PAIRWISE_DTYPE, WINDOW_DTYPE, fixed_windows,  # noqa: F401
+from . import distributed  # noqa: F401
+from .engine import (Comm, scan_sharded, shard_windows_c,  # noqa: F401
+                     BitMatrix, Context, ScanPlan, STATS_DTYPE, PAIRWISE_DTYPE, WINDOW_DTYPE, fixed_windows,  # noqa: F401
                      make_windows, mask_from_indices, pack_hap_major, pack_mask, unpack_hap_major)
 
 __version__ = "0.1.0"

@@ -102,6 +102,17 @@ SIGNATURES = {
     "impop_scan_plan_launch": (C.c_int, [_vp, _vp]),
     "impop_scan_plan_fetch": (C.c_int, [_vp, C.POINTER(WindowStats)]),
     "impop_scan_plan_info": (C.c_int, [_vp, _u64p, _u64p]),
+    "impop_scan_plan_device_records": (C.c_int, [_vp, C.POINTER(_vp)]),
+    "impop_shard_range": (C.c_int, [C.c_uint64, C.c_int, C.c_int, _u64p, _u64p]),
+    "impop_shard_windows": (C.c_int, [C.POINTER(Window), C.c_uint64, C.c_int, C.c_int, _u64p, _u64p, _u64p, _u64p]),
+    "impop_scan_sharded": (C.c_int, [C.POINTER(_vp), C.POINTER(_vp), _u64p, C.c_int, C.POINTER(Window), C.c_uint64, _u64p, _u64p,
+                                     _u64p, C.POINTER(ScanParams), C.POINTER(WindowStats)]),
+    "impop_comm_unique_id": (C.c_int, [C.c_char_p]),
+    "impop_comm_create": (C.c_int, [_vp, C.c_char_p, C.c_int, C.c_int, C.POINTER(_vp)]),
+    "impop_comm_destroy": (C.c_int, [_vp]),
+    "impop_gather": (C.c_int, [_vp, _vp, C.c_size_t, _vp]),
+    "impop_gather_records": (C.c_int, [_vp, _vp, C.c_uint64, C.POINTER(WindowStats)]),
+    "impop_allreduce_i64": (C.c_int, [_vp, _vp, C.c_size_t]),
     "impop_scan_plan_timing": (C.c_int, [_vp, C.c_int]),
     "impop_scan_plan_elapsed": (C.c_int, [_vp, _f64p, _u64p]),
     "impop_scan_plan_destroy": (C.c_int, [_vp]),

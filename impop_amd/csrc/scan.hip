@@ -207,191 +207,121 @@ __global__ __launch_bounds__(256, IMPOP_SCAN_MIN_WAVES) void scan_tiles_kernel(c
     tile_reduce_store(wide, out);
 }
 
-// Any wps (n > 512 haplotypes): the haplotype axis is walked in chunks of 16 dwords whose three
-// masks sit in SGPRs (48 scalar registers, loaded once per chunk per workgroup); inside a chunk the
-// wave streams the 4 granules of each of ITS blocks (<= SB_MAX blocks per wave and tile) and keeps
-// per-block partial counts in registers; the products are formed once all chunks are in.  Every
-// byte of the tile is still read exactly once, in 1 KiB coalesced pieces.  (The first version
-// re-loaded the masks granule by granule and reached 5.6 TB/s on 4096 haplotypes.)
-constexpr int SB_MAX = 8;   // blocks per wave per tile => tile_blocks <= 32 for this kernel
-constexpr int SB_CH = 16;   // dwords per chunk
+// Any wps (n > 512 haplotypes, and every weighted matrix): the three masks of the WHOLE haplotype axis sit in
+// LDS (3 x wps dwords, <= 24 KB at the 65 535-haplotype limit; filled once per workgroup) and come back as
+// broadcast ds_read_b128 — every lane the same address, no bank conflict — so a wave simply streams the
+// granules of one 64-site block after the other, AN_U fully coalesced 1 KiB loads in flight, with the four
+// per-site counts in registers for the length of the block.  Every byte of the tile is read exactly once.
+// (Round 1 walked the haplotype axis in 16-dword chunks whose masks were re-loaded into SGPRs per chunk for up
+// to 8 blocks per wave: 6.08 TB/s on the 4096 x 10^7 launch, and tiles were pinned to 32 blocks = 1 MB, which
+// left a fifth of the chip idle in the last wave of tiles.)
+// WEIGHTED (impop_matrix_set_site_weights): column s stands for w_s base pairs (a graph node of that length), so
+// every sum_s c (n - c) becomes sum_s w_s c (n - c) and the window's W is sum_s w_s (host prefix sums at plan
+// time) — exactly what scanning the bp-expanded matrix gives — while the segregating-site counts stay counts
+// of COLUMNS (variable nodes, what a VCF of the window lists).
+constexpr int AN_U = 8;  // granules (1 KiB wave loads) in flight per wave
 
-#ifndef IMPOP_SCAN_GENERIC_WAVES
-#define IMPOP_SCAN_GENERIC_WAVES 4
-#endif
-__global__ __launch_bounds__(256, IMPOP_SCAN_GENERIC_WAVES) void scan_tiles_generic_kernel(const uint32_t *__restrict__ sb,
-                                                                    const ScanTile *__restrict__ tiles,
-                                                                    const uint32_t *__restrict__ masks, uint32_t wps,
-                                                                    uint32_t G, uint32_t r, const PopSizes ps,
-                                                                    TilePartial *__restrict__ out) {
+template <bool SUBSET_P>
+__device__ __forceinline__ void anyn_granule(const u32v4 v, const uint32_t *lp, const uint32_t *la, const uint32_t *lb,
+                                             uint32_t g, uint32_t &c, uint32_t &cP, uint32_t &cA, uint32_t &cB) {
+    const u32v4 ka = *reinterpret_cast<const u32v4 *>(la + 4 * g);  // broadcast LDS reads
+    const u32v4 kb = *reinterpret_cast<const u32v4 *>(lb + 4 * g);
+    c += __popc(v.x) + __popc(v.y) + __popc(v.z) + __popc(v.w);
+    cA += __popc(v.x & ka.x) + __popc(v.y & ka.y) + __popc(v.z & ka.z) + __popc(v.w & ka.w);
+    cB += __popc(v.x & kb.x) + __popc(v.y & kb.y) + __popc(v.z & kb.z) + __popc(v.w & kb.w);
+    if (SUBSET_P) {
+        const u32v4 kp = *reinterpret_cast<const u32v4 *>(lp + 4 * g);
+        cP += __popc(v.x & kp.x) + __popc(v.y & kp.y) + __popc(v.z & kp.z) + __popc(v.w & kp.w);
+    }
+}
+
+template <bool SUBSET_P, bool WEIGHTED>
+__global__ __launch_bounds__(256, 4) void scan_tiles_anyn_kernel(const uint32_t *__restrict__ sb, const ScanTile *__restrict__ tiles,
+                                                                 const uint32_t *__restrict__ masks, uint32_t wps, uint32_t G,
+                                                                 uint32_t r, const PopSizes ps, const uint32_t *__restrict__ weights,
+                                                                 TilePartial *__restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t an_lds[];  // p | a | b, each padded to a multiple of 4 dwords
+    const uint32_t wps4 = (wps + 3) & ~3u;
+    uint32_t *lp = an_lds, *la = an_lds + wps4, *lb = an_lds + 2 * wps4;
+    for (uint32_t k = threadIdx.x; k < wps4; k += 256) {
+        const bool in = k < wps;
+        lp[k] = in ? masks[k] : 0u; la[k] = in ? masks[wps + k] : 0u; lb[k] = in ? masks[2 * wps + k] : 0u;
+    }
+    __syncthreads();
     const ScanTile t = tiles[blockIdx.x];
     const uint64_t b0 = t.site_begin >> 6, b1 = (t.site_end + 63) >> 6;
     const uint32_t lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint32_t *mp = masks, *ma = masks + wps, *mb = masks + 2 * wps;
-    uint32_t cnt[SB_MAX][4];
-#pragma unroll
-    for (int j = 0; j < SB_MAX; ++j) cnt[j][0] = cnt[j][1] = cnt[j][2] = cnt[j][3] = 0;
-    const uint32_t full_chunks = (G > 0 ? (G - 1) : 0) / (SB_CH / 4);  // chunks made of full 16-byte granules only
-    for (uint32_t ch = 0; ch < full_chunks; ++ch) {
-        uint32_t kp[SB_CH], ka[SB_CH], kb[SB_CH];
-#pragma unroll
-        for (int k = 0; k < SB_CH; ++k) { kp[k] = mp[ch * SB_CH + k]; ka[k] = ma[ch * SB_CH + k]; kb[k] = mb[ch * SB_CH + k]; }
-#pragma unroll
-        for (int j = 0; j < SB_MAX; ++j) {
-            const uint64_t b = b0 + wave + 4 * j;
-            if (b < b1) {  // wave-uniform
-                const uint32_t *blk = sb + b * 64ull * wps + (uint64_t)ch * (SB_CH / 4) * 256 + lane * 4;
-                u32v4 v[SB_CH / 4];
-#pragma unroll
-                for (int g = 0; g < SB_CH / 4; ++g) v[g] = stream_load(reinterpret_cast<const u32v4 *>(blk + g * 256));
-#pragma unroll
-                for (int g = 0; g < SB_CH / 4; ++g) {
-                    const uint32_t w4[4] = {v[g].x, v[g].y, v[g].z, v[g].w};
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        cnt[j][0] += __popc(w4[e]);
-                        cnt[j][1] += __popc(w4[e] & kp[4 * g + e]);
-                        cnt[j][2] += __popc(w4[e] & ka[4 * g + e]);
-                        cnt[j][3] += __popc(w4[e] & kb[4 * g + e]);
-                    }
-                }
-            }
-        }
-    }
-    // remaining granules (fewer than a chunk) and the short last granule, granule by granule
+    const uint32_t Gf = G - 1;  // full 16-byte granules; the last granule holds r = 1..4 dwords per site
     LaneAcc acc;
+    for (uint64_t b = b0 + wave; b < b1; b += 4) {
+        const uint32_t *blk = sb + b * 64ull * wps + lane * 4;
+        uint32_t c = 0, cP = 0, cA = 0, cB = 0;
+        uint32_t g = 0;
+        for (; g + AN_U <= Gf; g += AN_U) {
+            u32v4 v[AN_U];
 #pragma unroll
-    for (int j = 0; j < SB_MAX; ++j) {
-        const uint64_t b = b0 + wave + 4 * j;
-        if (b < b1) {
-            const uint32_t *blk = sb + b * 64ull * wps;
-            uint32_t c = cnt[j][0], cP = cnt[j][1], cA = cnt[j][2], cB = cnt[j][3];
-            for (uint32_t g = full_chunks * (SB_CH / 4); g + 1 < G; ++g) {
-                const u32v4 v = stream_load(reinterpret_cast<const u32v4 *>(blk + (uint64_t)g * 256 + lane * 4));
-                const uint32_t k = 4 * g;
-                c += __popc(v.x) + __popc(v.y) + __popc(v.z) + __popc(v.w);
-                cP += __popc(v.x & mp[k]) + __popc(v.y & mp[k + 1]) + __popc(v.z & mp[k + 2]) + __popc(v.w & mp[k + 3]);
-                cA += __popc(v.x & ma[k]) + __popc(v.y & ma[k + 1]) + __popc(v.z & ma[k + 2]) + __popc(v.w & ma[k + 3]);
-                cB += __popc(v.x & mb[k]) + __popc(v.y & mb[k + 1]) + __popc(v.z & mb[k + 2]) + __popc(v.w & mb[k + 3]);
-            }
-            const uint32_t *last = blk + (uint64_t)(G - 1) * 256 + lane * r;
-            for (uint32_t e = 0; e < r; ++e) {
-                const uint32_t v = stream_load(last + e), k = 4 * (G - 1) + e;
-                c += __popc(v); cP += __popc(v & mp[k]); cA += __popc(v & ma[k]); cB += __popc(v & mb[k]);
-            }
-            const uint64_t s = b * 64 + lane;
-            if (s >= t.site_begin && s < t.site_end) {
-                acc.s_all += (c != 0 && c != ps.n);
-                acc.s_p += (cP != 0 && cP != ps.nP);
-                acc.s_a += (cA != 0 && cA != ps.nA);
-                acc.s_b += (cB != 0 && cB != ps.nB);
-                acc.q_p += cP * (ps.nP - cP);
-                acc.q_a += cA * (ps.nA - cA);
-                acc.q_b += cB * (ps.nB - cB);
-                acc.q_ab += cA * (ps.nB - cB) + cB * (ps.nA - cA);
+            for (int u = 0; u < AN_U; ++u) v[u] = stream_load(reinterpret_cast<const u32v4 *>(blk + (uint64_t)(g + u) * 256));
+#pragma unroll
+            for (int u = 0; u < AN_U; ++u) anyn_granule<SUBSET_P>(v[u], lp, la, lb, g + u, c, cP, cA, cB);
+        }
+        for (; g < Gf; ++g)
+            anyn_granule<SUBSET_P>(stream_load(reinterpret_cast<const u32v4 *>(blk + (uint64_t)g * 256)), lp, la, lb, g, c, cP, cA, cB);
+        const uint32_t *last = sb + b * 64ull * wps + (uint64_t)Gf * 256 + lane * r;
+        for (uint32_t e = 0; e < r; ++e) {
+            const uint32_t v = stream_load(last + e), k = 4 * Gf + e;
+            c += __popc(v); cA += __popc(v & la[k]); cB += __popc(v & lb[k]);
+            if (SUBSET_P) cP += __popc(v & lp[k]);
+        }
+        if (!SUBSET_P) cP = c;
+        const uint64_t s = b * 64 + lane;
+        if (s >= t.site_begin && s < t.site_end) {  // only the first / last block of a tile is partial
+            acc.s_all += (c - 1u) < (ps.n - 1u);
+            acc.s_p += (cP - 1u) < (ps.nP - 1u);
+            acc.s_a += (cA - 1u) < (ps.nA - 1u);
+            acc.s_b += (cB - 1u) < (ps.nB - 1u);
+            // n <= 65535: every product is below 2^32
+            const uint32_t qp = cP * (ps.nP - cP), qa = cA * (ps.nA - cA), qb = cB * (ps.nB - cB);
+            const uint64_t qab = (uint64_t)(cA * (ps.nB - cB)) + (uint64_t)(cB * (ps.nA - cA));
+            if (WEIGHTED) {
+                const uint64_t wt = weights[s];
+                acc.q_p += wt * qp; acc.q_a += wt * qa; acc.q_b += wt * qb; acc.q_ab += wt * qab;
+            } else {
+                acc.q_p += qp; acc.q_a += qa; acc.q_b += qb; acc.q_ab += qab;
             }
         }
     }
     tile_reduce_store(acc, out);
 }
 
-// Weighted sites (impop_matrix_set_site_weights): column s stands for w_s base pairs (a graph node of
-// that length), so every sum_s c (n - c) becomes sum_s w_s c (n - c) and the window's W is sum_s w_s (taken
-// from host prefix sums when the plan is built) — exactly what scanning the bp-expanded matrix gives —
-// while the segregating-site counts stay counts of
-// COLUMNS (variable nodes, what a VCF of the window lists).  Node-level matrices are small; this kernel
-// takes any wps with masks read from memory and is not the tuned hot path.
-__global__ __launch_bounds__(256) void scan_tiles_weighted_kernel(const uint32_t *__restrict__ sb, const ScanTile *__restrict__ tiles,
-                                                                  const uint32_t *__restrict__ masks, uint32_t wps, uint32_t G,
-                                                                  uint32_t r, const PopSizes ps, const uint32_t *__restrict__ weights,
-                                                                  TilePartial *__restrict__ out) {
-    __shared__ uint64_t red[4][8];
-    const ScanTile t = tiles[blockIdx.x];
-    const uint64_t b0 = t.site_begin >> 6, b1 = (t.site_end + 63) >> 6;
-    const uint32_t lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint32_t *mp = masks, *ma = masks + wps, *mb = masks + 2 * wps;
-    uint64_t acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // s_all, s_p, s_a, s_b, q_p, q_a, q_b, q_ab
-    for (uint64_t b = b0 + wave; b < b1; b += 4) {
-        const uint32_t *blk = sb + b * 64ull * wps;
-        uint32_t c = 0, cP = 0, cA = 0, cB = 0;
-        for (uint32_t g = 0; g + 1 < G; ++g) {
-            const u32v4 v = stream_load(reinterpret_cast<const u32v4 *>(blk + (uint64_t)g * 256 + lane * 4));
-            const uint32_t w4[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const uint32_t k = 4 * g + e;
-                c += __popc(w4[e]); cP += __popc(w4[e] & mp[k]); cA += __popc(w4[e] & ma[k]); cB += __popc(w4[e] & mb[k]);
-            }
-        }
-        for (uint32_t e = 0; e < r; ++e) {
-            const uint32_t v = stream_load(blk + (uint64_t)(G - 1) * 256 + lane * r + e), k = 4 * (G - 1) + e;
-            c += __popc(v); cP += __popc(v & mp[k]); cA += __popc(v & ma[k]); cB += __popc(v & mb[k]);
-        }
-        const uint64_t s = b * 64 + lane;
-        if (s >= t.site_begin && s < t.site_end) {
-            const uint64_t wt = weights[s];
-            acc[0] += (c - 1u) < (ps.n - 1u); acc[1] += (cP - 1u) < (ps.nP - 1u);
-            acc[2] += (cA - 1u) < (ps.nA - 1u); acc[3] += (cB - 1u) < (ps.nB - 1u);
-            acc[4] += wt * ((uint64_t)cP * (ps.nP - cP));
-            acc[5] += wt * ((uint64_t)cA * (ps.nA - cA));
-            acc[6] += wt * ((uint64_t)cB * (ps.nB - cB));
-            acc[7] += wt * ((uint64_t)cA * (ps.nB - cB) + (uint64_t)cB * (ps.nA - cA));
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const uint64_t v = wave_sum_u64(acc[i]);
-        if (lane == 0) red[wave][i] = v;
-    }
-    __syncthreads();
-    if (threadIdx.x < 8) {
-        const uint64_t v = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
-        TilePartial *o = out + blockIdx.x;
-        switch (threadIdx.x) {
-            case 0: o->s_all = (uint32_t)v; break;
-            case 1: o->s_p = (uint32_t)v; break;
-            case 2: o->s_a = (uint32_t)v; break;
-            case 3: o->s_b = (uint32_t)v; break;
-            case 4: o->sum_p = v; break;
-            case 5: o->sum_a = v; break;
-            case 6: o->sum_b = v; break;
-            default: o->sum_ab = v; break;
-        }
-    }
-}
+// TPW threads per window sum its tile partials (integers: any order gives the same totals), then one thread
+// runs the fp64 epilogue.  Same operation order as oracle_window_sitecount (oracle/impop_oracle.c) which restates
+// pica2.py:154,164, h-fst.py:203-240 and tj_d.py:53-65 on the exact pair sums.  TPW = 1 for the usual many-
+// windows-of-a-few-tiles shape, 64 (a wave per window) / 256 (a workgroup per window) when windows span many
+// tiles — BASELINE config 5's single 10^7-site window is ~19 500 tiles, a 0.9 MB read that one thread would
+// walk serially behind the streaming kernel.
+struct WinTotals {
+    uint32_t s_all, s_p, s_a, s_b;
+    uint64_t sum_p, sum_a, sum_b, sum_ab;
+};
 
-// One thread per window: integer totals, then the fp64 epilogue.  Same operation order as
-// oracle_window_sitecount (oracle/impop_oracle.c) which restates pica2.py:154,164,
-// h-fst.py:203-240 and tj_d.py:53-65 on the exact pair sums.
-__global__ void scan_finalize_kernel(const TilePartial *__restrict__ parts, const WinDesc *__restrict__ wins,
-                                     uint64_t n_windows, PopSizes ps, const double *__restrict__ taj, int d_pi_mode,
-                                     int s_scope, impop_window_stats *__restrict__ out) {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_windows) return;
-    const WinDesc w = wins[i];
-    uint32_t s_all = 0, s_p = 0, s_a = 0, s_b = 0;
-    uint64_t sum_p = 0, sum_a = 0, sum_b = 0, sum_ab = 0;
-    for (uint64_t t = w.t0; t < w.t1; ++t) {
-        const TilePartial p = parts[t];
-        s_all += p.s_all; s_p += p.s_p; s_a += p.s_a; s_b += p.s_b;
-        sum_p += p.sum_p; sum_a += p.sum_a; sum_b += p.sum_b; sum_ab += p.sum_ab;
-    }
+__device__ inline void window_epilogue(const WinDesc &w, const WinTotals &T, const PopSizes &ps, const double *__restrict__ taj,
+                                       int d_pi_mode, int s_scope, impop_window_stats *__restrict__ dst) {
     const uint64_t n_sites = w.n_sites;  // window length, or the sum of its columns' weights (window_weights)
     impop_window_stats r;
-    r.n_sites = (uint32_t)n_sites;
-    r.s_all = s_all; r.s_p = s_p; r.s_a = s_a; r.s_b = s_b; r.flags = 0;
-    r.sum_p = sum_p; r.sum_a = sum_a; r.sum_b = sum_b; r.sum_ab = sum_ab;
+    r.n_sites = (uint32_t)n_sites;       // <= 2^32 - 1 by the plan-time checks
+    r.s_all = T.s_all; r.s_p = T.s_p; r.s_a = T.s_a; r.s_b = T.s_b; r.flags = 0;
+    r.sum_p = T.sum_p; r.sum_a = T.sum_a; r.sum_b = T.sum_b; r.sum_ab = T.sum_ab;
     const double nan = __builtin_nan("");
     const double W = (double)n_sites;
     const double seq_len = (double)w.seq_len;
     const double nP = (double)ps.nP, nA = (double)ps.nA, nB = (double)ps.nB;
     const double pairsP = nP * (double)(ps.nP - 1) / 2.0;
-    const double pi = (ps.nP >= 2 && W > 0) ? (double)sum_p / (pairsP * W) : 0.0;
+    const double pi = (ps.nP >= 2 && W > 0) ? (double)T.sum_p / (pairsP * W) : 0.0;
     const double pi_site = (seq_len != 0.0) ? pi / seq_len : nan;
     const double pairsA = nA * (nA - 1.0) / 2.0, pairsB = nB * (nB - 1.0) / 2.0;
-    double pi_a = (ps.nA >= 2 && W > 0) ? (double)sum_a / (pairsA * W) : 0.0;
-    double pi_b = (ps.nB >= 2 && W > 0) ? (double)sum_b / (pairsB * W) : 0.0;
-    double dxy = (ps.nA && ps.nB && W > 0) ? (double)sum_ab / (nA * nB * W) : 0.0;
+    double pi_a = (ps.nA >= 2 && W > 0) ? (double)T.sum_a / (pairsA * W) : 0.0;
+    double pi_b = (ps.nB >= 2 && W > 0) ? (double)T.sum_b / (pairsB * W) : 0.0;
+    double dxy = (ps.nA && ps.nB && W > 0) ? (double)T.sum_ab / (nA * nB * W) : 0.0;
     double pi_xy = 0.5 * (pi_a + pi_b);
     const double fst = (dxy > 0) ? (dxy - pi_xy) / dxy : 0.0;
     double da = dxy - pi_xy;
@@ -399,7 +329,7 @@ __global__ void scan_finalize_kernel(const TilePartial *__restrict__ parts, cons
         pi_a /= seq_len; pi_b /= seq_len; da = (dxy - pi_xy) / seq_len; pi_xy /= seq_len; dxy /= seq_len;
     }
     r.pi = pi; r.pi_site = pi_site; r.pi_a = pi_a; r.pi_b = pi_b; r.pi_xy = pi_xy; r.dxy = dxy; r.da = da; r.fst = fst;
-    const double S = (double)(s_scope == 0 ? s_all : s_p);
+    const double S = (double)(s_scope == 0 ? T.s_all : T.s_p);
     const double pin = d_pi_mode == 0 ? py_round(pi_site, 8) : d_pi_mode == 1 ? pi_site : pi * W;
     double D = nan;
     if (ps.nP >= 2 && pin == pin) {
@@ -408,7 +338,42 @@ __global__ void scan_finalize_kernel(const TilePartial *__restrict__ parts, cons
         D = tajima_d_from(c, S, pin, nullptr, nullptr);
     }
     r.tajima_d = D;
-    out[i] = r;
+    *dst = r;
+}
+
+template <int TPW>
+__global__ __launch_bounds__(TPW == 1 ? 128 : 256) void scan_finalize_kernel(const TilePartial *__restrict__ parts,
+                                                                             const WinDesc *__restrict__ wins, uint64_t n_windows,
+                                                                             PopSizes ps, const double *__restrict__ taj,
+                                                                             int d_pi_mode, int s_scope,
+                                                                             impop_window_stats *__restrict__ out) {
+    constexpr int BLOCK = TPW == 1 ? 128 : 256;
+    const uint64_t i = ((uint64_t)blockIdx.x * BLOCK + threadIdx.x) / TPW;  // uniform per wave for TPW >= 64
+    const uint32_t sub = threadIdx.x % TPW;
+    if (TPW < 256 && i >= n_windows) return;
+    const WinDesc w = wins[i];
+    WinTotals T = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (uint64_t t = w.t0 + sub; t < w.t1; t += TPW) {
+        const TilePartial p = parts[t];
+        T.s_all += p.s_all; T.s_p += p.s_p; T.s_a += p.s_a; T.s_b += p.s_b;
+        T.sum_p += p.sum_p; T.sum_a += p.sum_a; T.sum_b += p.sum_b; T.sum_ab += p.sum_ab;
+    }
+    if (TPW >= 64) {
+        T.s_all = wave_sum_u32(T.s_all); T.s_p = wave_sum_u32(T.s_p); T.s_a = wave_sum_u32(T.s_a); T.s_b = wave_sum_u32(T.s_b);
+        T.sum_p = wave_sum_u64(T.sum_p); T.sum_a = wave_sum_u64(T.sum_a); T.sum_b = wave_sum_u64(T.sum_b);
+        T.sum_ab = wave_sum_u64(T.sum_ab);
+    }
+    if (TPW == 256) {
+        __shared__ WinTotals red[4];
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = T;
+        __syncthreads();
+        if (threadIdx.x == 0)
+            for (int k = 1; k < 4; ++k) {
+                T.s_all += red[k].s_all; T.s_p += red[k].s_p; T.s_a += red[k].s_a; T.s_b += red[k].s_b;
+                T.sum_p += red[k].sum_p; T.sum_a += red[k].sum_a; T.sum_b += red[k].sum_b; T.sum_ab += red[k].sum_ab;
+            }
+    }
+    if (sub == 0) window_epilogue(w, T, ps, taj, d_pi_mode, s_scope, out + i);
 }
 
 __global__ __launch_bounds__(256) void site_counts_kernel(const uint32_t *__restrict__ sb, const uint32_t *__restrict__ mask,
@@ -643,6 +608,7 @@ struct impop_scan_plan {
     bool subset_p = false;
     std::vector<uint32_t> masks;  // p | a | b, wps dwords each
     int d_pi_mode = 0, s_scope = 0;
+    int finalize_tpw = 1;  // threads per window of scan_finalize_kernel: 1, 64 or 256 by the longest tile range
     ScanTile *d_tiles = nullptr;
     WinDesc *d_wins = nullptr;
     TilePartial *d_parts = nullptr;
@@ -654,22 +620,31 @@ struct impop_scan_plan {
 };
 
 // W of every window in ORIGINAL coordinates: its length, or the sum of its columns' weights
-static void window_weights(const impop_matrix *m, const impop_window *windows, uint64_t n_windows, std::vector<WinDesc> &wd) {
+static int window_weights(const impop_matrix *m, const impop_window *windows, uint64_t n_windows, std::vector<WinDesc> &wd) {
     for (uint64_t i = 0; i < n_windows; ++i) {
-        if (!m->wt_prefix.empty()) wd[i].n_sites = m->wt_prefix[windows[i].site_end] - m->wt_prefix[windows[i].site_begin];
-        else if (m->compact) wd[i].n_sites = windows[i].site_end - windows[i].site_begin;
+        if (!m->wt_prefix.empty()) {
+            wd[i].n_sites = m->wt_prefix[windows[i].site_end] - m->wt_prefix[windows[i].site_begin];
+            // impop_window_stats.n_sites is 32 bits wide: refuse rather than truncate (unweighted windows are
+            // checked against the same limit by their length)
+            REQUIRE(wd[i].n_sites <= 0xFFFFFFFFull, "window %llu: the weights of its columns add up to %llu >= 2^32; split the window",
+                    (unsigned long long)i, (unsigned long long)wd[i].n_sites);
+        } else if (m->compact) {
+            wd[i].n_sites = windows[i].site_end - windows[i].site_begin;
+        }
     }
+    return IMPOP_OK;
 }
 
 // Default tile: ~256 KB of matrix per workgroup, but never so large that a small job leaves CUs without
 // work (>= 16 tiles per CU wanted), and never below the 32 blocks the kernel was tuned with.
 static uint32_t default_tile_blocks(const impop_ctx *ctx, const impop_matrix *m, const impop_window *windows, uint64_t n_windows) {
-    const uint32_t by_bytes = std::max<uint32_t>(32, 1024 / m->g.wps);
+    // ~256 KB per tile; wide sites (the any-n kernel, wps > 16) go down to 4 blocks = one per wave
+    const uint32_t by_bytes = m->g.wps > 16 ? std::max<uint32_t>(4, 1024 / m->g.wps) : std::max<uint32_t>(32, 1024 / m->g.wps);
     uint64_t blocks = 0;
     for (uint64_t i = 0; i < n_windows; ++i) blocks += (windows[i].site_end - windows[i].site_begin + 63) / 64;
     if (m->compact && blocks > m->g.n_block) blocks = m->g.n_block;
     const uint64_t by_parallelism = blocks / (16ull * (uint64_t)(ctx->n_cu > 0 ? ctx->n_cu : 256));
-    return (uint32_t)std::max<uint64_t>(32, std::min<uint64_t>(by_bytes, by_parallelism));
+    return (uint32_t)std::max<uint64_t>(std::min<uint32_t>(32, by_bytes), std::min<uint64_t>(by_bytes, by_parallelism));
 }
 
 // subset masks of a plan; the overlap of A and B is removed from both (h-fst.py:181-185)
@@ -731,7 +706,6 @@ IMPOP_API int impop_scan_plan_create(impop_ctx *ctx, const impop_matrix *m, cons
     // n = 32 ran at 2.6 TB/s with 32-block tiles and 5.0 TB/s with whole-window tiles
     uint32_t tile_blocks = prm.tile_blocks ? prm.tile_blocks : default_tile_blocks(ctx, m, windows, n_windows);
     REQUIRE(tile_blocks <= 4096, "impop_scan_params.tile_blocks too large");
-    if (m->g.wps > 16 && tile_blocks > 4 * SB_MAX) tile_blocks = 4 * SB_MAX;  // the any-n kernel keeps <= 8 blocks per wave in registers
     for (uint64_t i = 0; i < n_windows; ++i) {
         REQUIRE(windows[i].site_begin <= windows[i].site_end && windows[i].site_end <= matrix_span(m),
                 "window %llu: bad site range [%llu,%llu) for %llu sites", (unsigned long long)i,
@@ -754,13 +728,19 @@ IMPOP_API int impop_scan_plan_create(impop_ctx *ctx, const impop_matrix *m, cons
         std::vector<impop_window> mapped;  // compacted matrix: original coordinates -> kept-site index ranges
         map_windows(m, windows, n_windows, mapped);
         build_tiles(mapped.data(), n_windows, tile_blocks, wps, tiles, wd, p->bytes_streamed);
-        window_weights(m, windows, n_windows, wd);
     }
     p->n_tiles = tiles.size();
     auto fail = [&](int code) {
         impop_scan_plan_destroy(p);
         return code;
     };
+    {
+        const int wrc = window_weights(m, windows, n_windows, wd);
+        if (wrc) return fail(wrc);
+    }
+    uint64_t longest_range = 0;
+    for (const WinDesc &w : wd) longest_range = std::max(longest_range, w.t1 - w.t0);
+    p->finalize_tpw = longest_range > 2048 ? 256 : longest_range > 48 ? 64 : 1;
     if (p->n_tiles >= 0x7FFFFFFFull) {
         set_error("impop_scan: %llu tiles exceed one launch; raise tile_blocks", (unsigned long long)p->n_tiles);
         return fail(IMPOP_E_INVALID);
@@ -816,28 +796,38 @@ IMPOP_API int impop_scan_plan_launch(impop_scan_plan *p, void *d_out) {
         HIP_TRY(hipEventRecord(ev0, st));
     }
     const bool weighted = !p->m->wt_prefix.empty();  // W of each window came from the host prefix sums at plan time
-    if (p->n_tiles && weighted) {
-        hipLaunchKernelGGL(scan_tiles_weighted_kernel, dim3((uint32_t)p->n_tiles), dim3(256), 0, st, p->m->d_sb, p->d_tiles,
-                           p->d_masks, p->m->g.wps, p->m->g.G, p->m->g.r, p->ps, p->m->d_wt, p->d_parts);
+    const uint32_t wps = p->m->g.wps;
+    if (p->n_tiles && (weighted || wps > 16)) {
+        const size_t lds = (size_t)3 * ((wps + 3) & ~3u) * 4;
+#define ANYN(SP, WT)                                                                                                     \
+    hipLaunchKernelGGL((scan_tiles_anyn_kernel<SP, WT>), dim3((uint32_t)p->n_tiles), dim3(256), lds, st, p->m->d_sb,     \
+                       p->d_tiles, p->d_masks, wps, p->m->g.G, p->m->g.r, p->ps, p->m->d_wt, p->d_parts)
+        if (weighted) { if (p->subset_p) ANYN(true, true); else ANYN(false, true); }
+        else          { if (p->subset_p) ANYN(true, false); else ANYN(false, false); }
+#undef ANYN
         HIP_TRY(hipGetLastError());
         if (ev1) HIP_TRY(hipEventRecord(ev1, st));
     } else if (p->n_tiles) {
-        switch (p->m->g.wps) {
+        switch (wps) {
 #define CASE(W) case W: launch_scan_fixed<W>(p, st); break;
             CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8)
             CASE(9) CASE(10) CASE(11) CASE(12) CASE(13) CASE(14) CASE(15) CASE(16)
 #undef CASE
-            default:
-                hipLaunchKernelGGL(scan_tiles_generic_kernel, dim3((uint32_t)p->n_tiles), dim3(256), 0, st, p->m->d_sb,
-                                   p->d_tiles, p->d_masks, p->m->g.wps, p->m->g.G, p->m->g.r, p->ps, p->d_parts);
         }
         HIP_TRY(hipGetLastError());
         if (ev1) HIP_TRY(hipEventRecord(ev1, st));
     }
     if (p->n_windows) {
         impop_window_stats *dst = d_out ? (impop_window_stats *)d_out : p->d_out;
-        hipLaunchKernelGGL(scan_finalize_kernel, dim3((uint32_t)((p->n_windows + 127) / 128)), dim3(128), 0, st, p->d_parts,
-                           p->d_wins, p->n_windows, p->ps, ctx->d_taj, p->d_pi_mode, p->s_scope, dst);
+        if (p->finalize_tpw == 1)
+            hipLaunchKernelGGL(scan_finalize_kernel<1>, dim3((uint32_t)((p->n_windows + 127) / 128)), dim3(128), 0, st, p->d_parts,
+                               p->d_wins, p->n_windows, p->ps, ctx->d_taj, p->d_pi_mode, p->s_scope, dst);
+        else if (p->finalize_tpw == 64)
+            hipLaunchKernelGGL(scan_finalize_kernel<64>, dim3((uint32_t)((p->n_windows + 3) / 4)), dim3(256), 0, st, p->d_parts,
+                               p->d_wins, p->n_windows, p->ps, ctx->d_taj, p->d_pi_mode, p->s_scope, dst);
+        else
+            hipLaunchKernelGGL(scan_finalize_kernel<256>, dim3((uint32_t)p->n_windows), dim3(256), 0, st, p->d_parts,
+                               p->d_wins, p->n_windows, p->ps, ctx->d_taj, p->d_pi_mode, p->s_scope, dst);
         HIP_TRY(hipGetLastError());
     }
     return IMPOP_OK;
@@ -849,6 +839,12 @@ IMPOP_API int impop_scan_plan_fetch(impop_scan_plan *p, impop_window_stats *out_
         HIP_TRY(hipMemcpyAsync(out_host, p->d_out, p->n_windows * sizeof(impop_window_stats), hipMemcpyDeviceToHost,
                                p->ctx->stream));
     HIP_TRY(hipStreamSynchronize(p->ctx->stream));
+    return IMPOP_OK;
+}
+
+IMPOP_API int impop_scan_plan_device_records(impop_scan_plan *p, void **d_records) {
+    REQUIRE(p && d_records, "impop_scan_plan_device_records: NULL argument");
+    *d_records = p->d_out;
     return IMPOP_OK;
 }
 
@@ -980,8 +976,8 @@ IMPOP_API int impop_scan_multi(impop_ctx *ctx, const impop_matrix *m, const impo
         std::vector<impop_window> mapped;
         map_windows(m, windows, n_windows, mapped);
         build_tiles(mapped.data(), n_windows, default_tile_blocks(ctx, m, windows, n_windows), wps, tiles, wd, bytes);
-
-        window_weights(m, windows, n_windows, wd);
+        const int wrc = window_weights(m, windows, n_windows, wd);
+        if (wrc) return wrc;
     }
     REQUIRE(tiles.size() < 0x7FFFFFFFull, "impop_scan_multi: too many tiles");
     const size_t nt = tiles.size();
@@ -1035,7 +1031,6 @@ IMPOP_API int impop_afs(impop_ctx *ctx, const impop_matrix *m, const impop_windo
                 "impop_afs: window %llu: bad site range", (unsigned long long)i);
         longest = std::max(longest, windows[i].site_end - windows[i].site_begin);
     }
-    REQUIRE(n_windows <= 65535, "impop_afs: at most 65535 windows per call");
     std::vector<uint32_t> mk;
     mask_to_dwords(mask, m->g.n_hap, m->g.wps, true, mk);
     const uint32_t bins = popcount_vec(mk) + 1;
@@ -1054,10 +1049,14 @@ IMPOP_API int impop_afs(impop_ctx *ctx, const impop_matrix *m, const impop_windo
     const uint64_t chunks = (longest + 4095) / 4096;
     if (chunks) {
         REQUIRE(chunks < 0x7FFFFFFFull, "impop_afs: window too long");
-        hipLaunchKernelGGL(afs_kernel, dim3((uint32_t)chunks, (uint32_t)n_windows), dim3(256), (size_t)bins * 4, ctx->stream,
-                           m->d_sb, (const uint32_t *)(base + o_mask), m->g.wps, m->g.G, m->g.r,
-                           (const impop_window *)(base + o_wins), bins, (uint32_t *)(base + o_out));
-        HIP_TRY(hipGetLastError());
+        // windows ride on gridDim.y (<= 65535): any number of windows goes out in batches of that many
+        for (uint64_t w0 = 0; w0 < n_windows; w0 += 65535) {
+            const uint32_t nw = (uint32_t)std::min<uint64_t>(65535, n_windows - w0);
+            hipLaunchKernelGGL(afs_kernel, dim3((uint32_t)chunks, nw), dim3(256), (size_t)bins * 4, ctx->stream, m->d_sb,
+                               (const uint32_t *)(base + o_mask), m->g.wps, m->g.G, m->g.r,
+                               (const impop_window *)(base + o_wins) + w0, bins, (uint32_t *)(base + o_out) + w0 * bins);
+            HIP_TRY(hipGetLastError());
+        }
     }
     HIP_TRY(hipMemcpyAsync(out_host, base + o_out, n_windows * bins * 4, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));

@@ -478,3 +478,100 @@ class ScanPlan:
             self.destroy()
         except Exception:
             pass
+
+
+# ---- multi-GPU entries of the C ABI ------------------------------------------------------------------
+
+def shard_windows_c(windows, n_shards: int, shard: int):
+    """impop_shard_windows -> (first_window, n_windows, slab_begin, slab_end)"""
+    w = make_windows(windows)
+    out = [C.c_uint64() for _ in range(4)]
+    check(_lib.load().impop_shard_windows(w.ctypes.data_as(C.POINTER(Window)), len(w), int(n_shards), int(shard),
+                                          *[C.byref(x) for x in out]))
+    return tuple(int(x.value) for x in out)
+
+
+def scan_sharded(slabs, slab_site_begin, windows, mask_p=None, mask_a=None, mask_b=None, d_pi_mode: int = 0, s_scope: int = 0,
+                 tile_blocks: int = 0) -> np.ndarray:
+    """One process, several contexts (impop_scan_sharded): slabs[k] is a BitMatrix resident on its own context and
+    holds the sites [slab_site_begin[k], ...) of the chromosome; `windows` in chromosome coordinates.  Returns the
+    records in the order of `windows`."""
+    lib = _lib.load()
+    w = make_windows(windows)
+    n = len(slabs)
+    n_hap = slabs[0].n_hap
+    ctxs = (C.c_void_p * n)(*[s.ctx.handle for s in slabs])
+    mats = (C.c_void_p * n)(*[s.handle for s in slabs])
+    begins = np.ascontiguousarray(slab_site_begin, dtype=np.uint64)
+    prm = ScanParams(C.sizeof(ScanParams), int(d_pi_mode), int(s_scope), int(tile_blocks))
+    kp, pp = _mask_ptr(mask_p, n_hap)
+    ka, pa = _mask_ptr(mask_a, n_hap)
+    kb, pb = _mask_ptr(mask_b, n_hap)
+    out = np.zeros(len(w), dtype=STATS_DTYPE)
+    check(lib.impop_scan_sharded(ctxs, mats, begins.ctypes.data_as(C.POINTER(C.c_uint64)), n,
+                                 w.ctypes.data_as(C.POINTER(Window)), len(w), pp, pa, pb, C.byref(prm),
+                                 out.ctypes.data_as(C.POINTER(WindowStats))))
+    return out
+
+
+def _preload_torch_rccl() -> None:
+    """One RCCL per process: if PyTorch-ROCm is installed, load ITS librccl (soname librccl.so.1) first, by path,
+    so that the library's dlopen("librccl.so.1") and a later `import torch` bind to the same copy."""
+    import importlib.util
+    import os
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec and spec.submodule_search_locations:
+        cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "librccl.so")
+        if os.path.exists(cand):
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+
+
+class Comm:
+    """One process per GPU: an RCCL communicator bound to a Context (impop_comm).  Rank 0 makes the id with
+    Comm.unique_id() and ships the 128 bytes to the other ranks out of band."""
+
+    ID_BYTES = 128
+
+    @staticmethod
+    def unique_id() -> bytes:
+        _preload_torch_rccl()
+        buf = C.create_string_buffer(Comm.ID_BYTES)
+        check(_lib.load().impop_comm_unique_id(buf))
+        return buf.raw
+
+    def __init__(self, ctx: Context, unique_id: bytes, world: int, rank: int):
+        if len(unique_id) != Comm.ID_BYTES:
+            raise ValueError("unique_id must be 128 bytes")
+        _preload_torch_rccl()
+        self.ctx, self.world, self.rank = ctx, int(world), int(rank)
+        self._h = C.c_void_p()
+        check(ctx._lib.impop_comm_create(ctx.handle, unique_id, int(world), int(rank), C.byref(self._h)))
+
+    def gather(self, d_local: int, bytes_per_rank: int, d_all: int) -> None:
+        """ncclAllGather on the context's stream (device pointers, no host sync)."""
+        check(self.ctx._lib.impop_gather(self._h, C.c_void_p(d_local), int(bytes_per_rank), C.c_void_p(d_all)))
+
+    def gather_records(self, plan: "ScanPlan", n_total_windows: int) -> np.ndarray:
+        """All-gather the records of `plan` (this rank's shard of n_total_windows) -> every window, global order."""
+        d = C.c_void_p()
+        check(self.ctx._lib.impop_scan_plan_device_records(plan._h, C.byref(d)))
+        out = np.zeros(int(n_total_windows), dtype=STATS_DTYPE)
+        check(self.ctx._lib.impop_gather_records(self._h, d, int(n_total_windows), out.ctypes.data_as(C.POINTER(WindowStats))))
+        return out
+
+    def allreduce_i64(self, d_values: int, count: int) -> None:
+        check(self.ctx._lib.impop_allreduce_i64(self._h, C.c_void_p(d_values), int(count)))
+
+    def close(self) -> None:
+        if self._h:
+            self.ctx._lib.impop_comm_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -223,6 +223,51 @@ int impop_site_counts(impop_ctx *ctx, const impop_matrix *m, const uint64_t *mas
 int impop_ehh(impop_ctx *ctx, const impop_matrix *m, uint64_t site_begin, uint64_t site_end, const uint64_t *mask,
               int reverse, double *ehh_out_host, uint32_t *n_members);
 
+/* Device address of the plan's internal record buffer (n_windows x impop_window_stats, written by launches
+ * with d_out == NULL): what a caller hands to impop_gather_records without owning any device memory itself. */
+int impop_scan_plan_device_records(impop_scan_plan *plan, void **d_records);
+
+/* ---- multi-GPU -----------------------------------------------------------------
+ * Replaces the serial per-window loops of run_tajd.sh:103-196, run_h-fst.sh:155-190 and run_pica2_impg.sh:126-190
+ * ACROSS GPUs: no statistic spans windows, so the window list is cut into contiguous ranges (the first
+ * n % shards ranges hold one window more), each GPU keeps only the slab of sites its windows touch (sliding
+ * windows: slabs overlap by the halo) and the only exchange is ONE all-gather of the 128-byte records. */
+
+/* items [first, first + count) of shard `shard` out of n_shards */
+int impop_shard_range(uint64_t n_items, int n_shards, int shard, uint64_t *first, uint64_t *count);
+/* the windows of a shard and the site range [slab_begin, slab_end) they touch (all outputs nullable) */
+int impop_shard_windows(const impop_window *windows, uint64_t n_windows, int n_shards, int shard, uint64_t *first_window,
+                        uint64_t *n_shard_windows, uint64_t *slab_begin, uint64_t *slab_end);
+
+/* One process driving n_ctx devices (or n_ctx contexts of one device).  slabs[k] lives on ctxs[k] and holds the
+ * sites [slab_site_begin[k], slab_site_begin[k] + its n_site) of the chromosome — at least the range
+ * impop_shard_windows reports for shard k.  `windows` are in chromosome coordinates.  Every context launches its
+ * pass before any result is waited for; out_host receives n_windows records in the order of `windows`, byte for
+ * byte what one context holding the whole matrix returns. */
+int impop_scan_sharded(impop_ctx *const *ctxs, const impop_matrix *const *slabs, const uint64_t *slab_site_begin, int n_ctx,
+                       const impop_window *windows, uint64_t n_windows, const uint64_t *mask_p, const uint64_t *mask_a,
+                       const uint64_t *mask_b, const impop_scan_params *params, impop_window_stats *out_host);
+
+/* One process per GPU: a communicator over RCCL (xGMI inside a node).  Rank 0 calls impop_comm_unique_id and
+ * hands the 128 bytes to the other ranks by any out-of-band means (file, MPI, the launcher's store); then every
+ * rank calls impop_comm_create with its context.  RCCL is loaded (dlopen librccl.so.1) by these two calls only. */
+#define IMPOP_COMM_ID_BYTES 128
+typedef struct impop_comm impop_comm;
+int impop_comm_unique_id(void *id_out /* IMPOP_COMM_ID_BYTES */);
+int impop_comm_create(impop_ctx *ctx, const void *unique_id, int world, int rank, impop_comm **out);
+int impop_comm_destroy(impop_comm *comm);
+/* ncclAllGather of bytes_per_rank bytes from every rank into d_all (world x bytes_per_rank, rank order); device
+ * pointers; enqueued on the context's stream behind the scans that wrote d_local — no host synchronisation. */
+int impop_gather(impop_comm *comm, const void *d_local, size_t bytes_per_rank, void *d_all);
+/* The scan's exchange step in one call: this rank's records (device pointer, the shard impop_shard_range gives
+ * this rank out of n_total_windows; e.g. impop_scan_plan_device_records) are all-gathered and every rank
+ * receives all n_total_windows records in global window order on the host.  Synchronises the stream. */
+int impop_gather_records(impop_comm *comm, const void *d_local_records, uint64_t n_total_windows,
+                         impop_window_stats *out_host);
+/* The one reduction of the path: a single giant window's Gram matrix, site axis split over
+ * ranks — in-place ncclAllReduce(sum) of `count` int64 on the device, on the context's stream. */
+int impop_allreduce_i64(impop_comm *comm, int64_t *d_values, size_t count);
+
 /* ---- all-pairs path -------------------------------------------------------
  * I_ij = #sites of the window carried by both i and j (the quantity behind
  * `impg similarity`'s estimated.identity, run_pica2_impg.sh:162); a_i = I_ii.

@@ -948,3 +948,125 @@ def test_hud_grouped_nontransitive_tables_reproduce_reference_seed_order(ctx):
                 assert rel_close(float(out[k]), fh(c["out"][key]), REL, 1e-300), (t["name"], run["hashseed"], key)
             checked += 1
     assert checked >= 50
+
+
+def test_scan_sharded_contexts_equal_one_context():
+    """impop_scan_sharded: the window list cut into contiguous ranges, one context + one slab per
+    range (the contexts share the test box's one device), every pass launched before the first fetch — records
+    byte-identical to one context holding the whole matrix, for disjoint and sliding (halo) windows, with a
+    subset mask, and for a shard count that leaves a shard empty."""
+    import impop_amd
+    from impop_amd import engine
+    n, W = 465, 64 * 300 + 17
+    c0 = impop_amd.Context(0)
+    whole = c0.synthetic(n, W, seed=77)
+    bits = whole.download()
+    rng = np.random.default_rng(5)
+    inA = (rng.random(n) < 0.3).astype(np.uint8); inB = (rng.random(n) < 0.3).astype(np.uint8)
+    inP = (rng.random(n) < 0.9).astype(np.uint8)
+    for size, step, shards, mp in ((1000, None, 2, None), (1000, 500, 3, inP), (4000, 1500, 4, None), (9000, None, 5, None)):
+        wins = impop_amd.fixed_windows(W, size, step)
+        want = whole.scan(wins, mp, inA, inB)
+        ctxs, slabs, begins = [], [], []
+        for k in range(shards):
+            first, cnt, s0, s1 = engine.shard_windows_c(wins, shards, k)
+            lo, hi = impop_amd.distributed.shard_range(len(wins), shards, k)
+            assert (first, first + cnt) == (lo, hi)  # the C rule is the Python rule
+            w0, w1 = s0 // 64, max((s1 + 63) // 64, s0 // 64 + 1)
+            ck = impop_amd.Context(0)
+            slabs.append(ck.upload(np.ascontiguousarray(bits[:, w0:w1]), min(64 * w1, W) - 64 * w0, keep_hap_major=False))
+            ctxs.append(ck); begins.append(64 * w0)
+        got = engine.scan_sharded(slabs, begins, wins, mp, inA, inB)
+        assert got.tobytes() == want.tobytes(), (size, step, shards)
+        # a slab that does not cover its shard is refused, not read out of bounds
+        if shards >= 2:
+            with pytest.raises(impop_amd.ImpopError):
+                engine.scan_sharded(slabs, [b + 64 for b in begins], wins, mp, inA, inB)
+        for s, ck in zip(slabs, ctxs):
+            s.free(); ck.close()
+    whole.free(); c0.close()
+
+
+def test_rccl_comm_one_rank_gather_and_allreduce():
+    """The one-process-per-GPU exchange of the C ABI (impop_comm_* over RCCL, loaded with dlopen) with the one
+    rank a one-GPU box allows: all-gather of raw device bytes on the context's stream directly behind the scan
+    that writes them, impop_gather_records (padding + global order), and the int64 all-reduce of the K-split Gram."""
+    import torch
+
+    import impop_amd
+    from impop_amd import engine
+    dev = torch.device("cuda", 0)
+    s = torch.cuda.Stream(dev)
+    ctx = impop_amd.Context(0, stream=s.cuda_stream)
+    comm = engine.Comm(ctx, engine.Comm.unique_id(), 1, 0)
+    n, NW, Wn = 465, 3000, 5000
+    bm = ctx.synthetic(n, NW * Wn, seed=3)
+    wins = impop_amd.fixed_windows(NW * Wn, Wn)
+    plan = bm.plan(wins, None, np.arange(n) < 100, np.arange(n) >= 300)
+    with torch.cuda.stream(s):
+        local = torch.zeros(NW * 128, dtype=torch.uint8, device=dev)
+        allb = torch.zeros(NW * 128, dtype=torch.uint8, device=dev)
+    s.synchronize()
+    for _ in range(3):  # scan (about a millisecond) and gather back to back on one stream, no host sync in between
+        plan.launch(local.data_ptr())
+        comm.gather(local.data_ptr(), NW * 128, allb.data_ptr())
+    s.synchronize()
+    want = bm.scan(wins, None, np.arange(n) < 100, np.arange(n) >= 300)
+    assert allb.cpu().numpy().tobytes() == want.tobytes()
+    plan.launch()
+    assert comm.gather_records(plan, NW).tobytes() == want.tobytes()
+    with torch.cuda.stream(s):
+        v = torch.arange(-500, 500, dtype=torch.int64, device=dev) * (1 << 40)
+    s.synchronize()
+    comm.allreduce_i64(v.data_ptr(), v.numel())
+    s.synchronize()
+    assert (v.cpu() == torch.arange(-500, 500, dtype=torch.int64) * (1 << 40)).all()
+    plan.destroy(); bm.free(); comm.close(); ctx.close()
+
+
+def test_window_spanning_many_tiles_uses_parallel_finalize(ctx, oracle):
+    """Few long windows (BASELINE config 5's single-window shape): the tile partials of a window are summed by a
+    wave (> 48 tiles) or a workgroup (> 2048 tiles) instead of one thread — integer sums, so the records cannot
+    depend on which; checked against the one-thread path (large tiles) and the oracle."""
+    n, W = 200, 64 * 5000 + 11
+    bm = ctx.synthetic(n, W, seed=21)
+    inA = np.arange(n) % 3 == 0; inB = np.arange(n) % 3 == 1
+    wins = [(0, W, W), (64 * 100 + 5, 64 * 4100, 999), (7, 64 * 40, 0)]
+    ref = bm.scan(wins, None, inA, inB, tile_blocks=4096)     # <= 2 tiles per window: one thread each
+    for tb in (64, 8, 2, 1):                                   # up to 5001 tiles for the first window
+        got = bm.scan(wins, None, inA, inB, tile_blocks=tb)
+        assert got.tobytes() == ref.tobytes(), tb
+    bits = bm.download()
+    ones = oracle.pack_mask(np.ones(n, np.uint8))
+    want = oracle.window_sitecount(bits, n, wins[1][0], wins[1][1], ones, oracle.pack_mask(inA), oracle.pack_mask(inB), 999)
+    check_record(ref[1], want, "long window")
+    bm.free()
+
+
+def test_weighted_window_beyond_u32_is_refused_and_afs_batches(ctx):
+    """impop_window_stats.n_sites is 32 bits: a weighted window whose weights add up to >= 2^32 is refused when the
+    plan is built (it used to be truncated silently); impop_afs takes any number of windows (it used to stop at
+    65 535, the grid's y limit)."""
+    import impop_amd
+    K = 3000
+    rng = np.random.default_rng(8)
+    nodes = (rng.random((20, K)) < 0.3).astype(np.uint8)
+    bn = ctx.upload_dense(nodes, keep_hap_major=False)
+    bn.set_site_weights(np.full(K, 2_000_000, dtype=np.uint32))   # 3000 x 2e6 = 6e9 > 2^32
+    with pytest.raises(impop_amd.ImpopError) as ei:
+        bn.scan([(0, K, 0)])
+    assert "2^32" in str(ei.value)
+    ok = bn.scan([(0, 2000, 0)])                                  # 4e9 < 2^32 still fits
+    assert int(ok[0]["n_sites"]) == 4_000_000_000
+    with pytest.raises(impop_amd.ImpopError):
+        bn.scan_multi([(0, K, 0)], [np.arange(20) < 10, np.arange(20) >= 10])
+    bn.free()
+    n, W = 33, 70_000
+    m = (rng.random((n, W)) < 0.2).astype(np.uint8)
+    bm = ctx.upload_dense(m, keep_hap_major=False)
+    wins = [(s, s + 1, 1) for s in range(W)]                      # 70 000 one-site windows
+    afs = bm.afs(wins)
+    c = m.sum(axis=0)
+    assert afs.shape == (W, n + 1) and (afs.sum(axis=1) == 1).all()
+    assert (afs[np.arange(W), c] == 1).all()
+    bm.free()

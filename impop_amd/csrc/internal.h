@@ -38,6 +38,8 @@ int hip_fail(hipError_t e, const char *what, const char *file, int line);
         }                                                                                                      \
     } while (0)
 
+void matrix_drop_derived(const impop_matrix *m);  // frees the lazily built weight planes / masked operand / site bitmap
+
 #define NOT_WEIGHTED(m, fn)                                                                  \
     do {                                                                                     \
         if (!(m)->wt_prefix.empty()) {                                                                   \
@@ -86,6 +88,10 @@ struct impop_ctx {
     double *d_taj = nullptr;
     int64_t taj_n = -1;
     uint32_t *d_queue = nullptr;  // 8 task-queue heads of the persistent Gram kernel
+    // side stream + fork/join events (created on first use): independent latency-bound epilogue kernels of the
+    // all-pairs path run next to each other instead of one after the other
+    hipStream_t side = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     // growable scratch
     void *scratch = nullptr;
     size_t scratch_bytes = 0;
@@ -106,6 +112,15 @@ struct impop_matrix {
     // compacted matrix (impop_matrix_compact): only the sites variable among all haplotypes were kept;
     // pos[k] = original index of kept site k (host copy for window mapping), n_site_orig = original length
     uint32_t *d_wt = nullptr;  // optional per-site weights (impop_matrix_set_site_weights), plain site order
+    // weighted all-pairs path (pairwise.hip), built on first use: bit planes of the weights over 32-site dwords
+    // (plane k, dword d: bit j = bit k of weight[32 d + j]) and one masked copy of the RB32 operand
+    mutable uint32_t *d_wplanes = nullptr;
+    mutable uint32_t wplane_bits = 0;     // planes that have any bit set
+    mutable uint64_t wplane_stride = 0;   // dwords per plane
+    mutable uint32_t *d_rb_masked = nullptr;
+    // lazily built bitmap of the sites that segregate among ALL haplotypes (bit s of dword s>>5), cached for the
+    // all-pairs path's S (pairwise.hip); dropped with the matrix
+    mutable uint32_t *d_segmap = nullptr;
     bool compact = false;
     uint64_t n_site_orig = 0;
     std::vector<uint64_t> pos;

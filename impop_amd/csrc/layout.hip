@@ -504,6 +504,16 @@ IMPOP_API int impop_matrix_compact(impop_ctx *ctx, const impop_matrix *in, impop
     return IMPOP_OK;
 }
 
+namespace impop {
+void matrix_drop_derived(const impop_matrix *m) {
+    if (m->d_wplanes) hipFree(m->d_wplanes);
+    if (m->d_rb_masked) hipFree(m->d_rb_masked);
+    if (m->d_segmap) hipFree(m->d_segmap);
+    m->d_wplanes = nullptr; m->d_rb_masked = nullptr; m->d_segmap = nullptr;
+    m->wplane_bits = 0; m->wplane_stride = 0;
+}
+}  // namespace impop
+
 IMPOP_API int impop_matrix_set_site_weights(impop_ctx *ctx, impop_matrix *m, const uint32_t *weights_host) {
     REQUIRE(ctx && m, "impop_matrix_set_site_weights: NULL argument");
     NOT_COMPACT(m, "impop_matrix_set_site_weights");
@@ -515,6 +525,7 @@ IMPOP_API int impop_matrix_set_site_weights(impop_ctx *ctx, impop_matrix *m, con
         HIP_TRY(hipFree(m->d_wt));
         m->d_wt = nullptr;
     }
+    matrix_drop_derived(m);  // weight planes / masked operand belong to the old weights
     m->wt_prefix.clear();
     if (!weights_host) return IMPOP_OK;
     // host prefix sums: a window's W = sum of its columns' weights, looked up when a plan is built
@@ -557,6 +568,7 @@ IMPOP_API int impop_matrix_free(impop_ctx *ctx, impop_matrix *m) {
     if (m->d_sb) hipFree(m->d_sb);
     if (m->d_rb) hipFree(m->d_rb);
     if (m->d_wt) hipFree(m->d_wt);
+    matrix_drop_derived(m);
     delete m;
     return IMPOP_OK;
 }

@@ -581,8 +581,8 @@ static bool gram_use_fp4() {
     return v;
 }
 
-static int launch_gram(impop_ctx *ctx, const impop_matrix *m, const GramWindow *d_wins, uint32_t n_win, int32_t *d_out,
-                       uint64_t max_window_sites) {
+static int launch_gram(impop_ctx *ctx, const impop_matrix *m, const uint32_t *d_rb, const GramWindow *d_wins, uint32_t n_win,
+                       int32_t *d_out, uint64_t max_window_sites) {
     const uint32_t T = m->n_hap_pad / GT;
     const uint32_t tasks_per_win = T * (T + 1) / 2;  // upper-triangular tile pairs
     // two waves per SIMD on every CU = 8 * n_cu resident waves; aim at >= 4 rounds of them so the
@@ -602,13 +602,175 @@ static int launch_gram(impop_ctx *ctx, const impop_matrix *m, const GramWindow *
     const uint64_t need_wg = ((uint64_t)n_win * tasks_per_win * ksplit + 3) / 4;
     const uint32_t grid = (uint32_t)std::max<uint64_t>(8, std::min<uint64_t>(2ull * n_cu, need_wg));
     if (gram_use_fp4())
-        hipLaunchKernelGGL(gram_fp4_kernel, dim3(grid), dim3(256), 0, ctx->stream, m->d_rb, m->rb_nb, T, tasks_per_win, n_win,
+        hipLaunchKernelGGL(gram_fp4_kernel, dim3(grid), dim3(256), 0, ctx->stream, d_rb, m->rb_nb, T, tasks_per_win, n_win,
                            ksplit, d_wins, d_out, m->n_hap_pad, (uint64_t)m->n_hap_pad * m->n_hap_pad, ctx->d_queue);
     else
-        hipLaunchKernelGGL(gram_mfma_kernel, dim3(grid), dim3(256), 0, ctx->stream, m->d_rb, m->rb_nb, T, tasks_per_win, n_win,
+        hipLaunchKernelGGL(gram_mfma_kernel, dim3(grid), dim3(256), 0, ctx->stream, d_rb, m->rb_nb, T, tasks_per_win, n_win,
                            ksplit, d_wins, d_out, m->n_hap_pad, (uint64_t)m->n_hap_pad * m->n_hap_pad, ctx->d_queue);
     HIP_TRY(hipGetLastError());
     return IMPOP_OK;
+}
+
+// ---- weighted sites on the all-pairs path ------------------------------------------------------------------
+// Column s stands for w_s base pairs (one column per graph node, impop_matrix_set_site_weights): what `impg
+// similarity` hands the reference is a bp-weighted node-sharing identity (run_pica2_impg.sh:162-175), i.e.
+//     I_ij = sum_s w_s b_is b_js.
+// Write w_s = sum_k 2^k w_ks with bit planes w_ks in {0,1}.  Masking the site axis with plane k gives a 0/1
+// matrix M_k = M & W_k whose plain Gram matrix is sum_s w_ks b_is b_js (w_ks^2 = w_ks), so
+//     I = sum_k 2^k Gram(M_k)
+// with the UNCHANGED matrix-core kernel: per plane one elementwise AND of the RB32 operand (only the cells the
+// batch touches), one Gram launch, one shifted integer accumulate.  Exact by construction (every partial Gram is
+// an exact integer; the sum is required to stay below 2^31 like the length of an unweighted window); planes
+// without any set bit are skipped, so node lengths below 2^p cost p Gram launches over the NODE-level matrix —
+// against mean-node-length times the MACs for the bp-expanded one.
+__global__ void weight_planes_kernel(const uint32_t *__restrict__ wt, uint64_t n_site, uint64_t n_dword, uint32_t n_plane,
+                                     uint32_t *__restrict__ planes, uint32_t *__restrict__ used_bits) {
+    const uint64_t d = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (d >= n_dword) return;
+    uint32_t any = 0;
+    uint32_t w[32];
+#pragma unroll
+    for (int j = 0; j < 32; ++j) {
+        const uint64_t s = 32 * d + j;
+        w[j] = s < n_site ? wt[s] : 0u;
+        any |= w[j];
+    }
+    for (uint32_t k = 0; k < n_plane; ++k) {
+        uint32_t bits = 0;
+#pragma unroll
+        for (int j = 0; j < 32; ++j) bits |= ((w[j] >> k) & 1u) << j;
+        planes[(uint64_t)k * n_dword + d] = bits;
+    }
+    if (any) atomicOr(used_bits, any);
+}
+
+// masked operand for plane k over the cells [cell_lo, cell_hi) of every 32-row group (one thread = one row's dword pair)
+__global__ void rb_mask_kernel(const uint32_t *__restrict__ rb, uint32_t *__restrict__ out, uint64_t rb_nb, uint32_t n_group,
+                               uint64_t cell_lo, uint64_t cell_hi, const uint32_t *__restrict__ plane, uint64_t n_dword) {
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t per_group = (cell_hi - cell_lo) * 32;
+    if (t >= per_group * n_group) return;
+    const uint64_t g = t / per_group, r = t % per_group, cell = cell_lo + r / 32;
+    const uint64_t at = ((g * rb_nb + cell) * 32 + (r & 31)) * 2;
+    const u32x2 v = *reinterpret_cast<const u32x2 *>(rb + at);
+    u32x2 o;
+    o.x = 2 * cell < n_dword ? v.x & plane[2 * cell] : 0u;
+    o.y = 2 * cell + 1 < n_dword ? v.y & plane[2 * cell + 1] : 0u;
+    *reinterpret_cast<u32x2 *>(out + at) = o;
+}
+
+__global__ void gram_accumulate_kernel(int32_t *__restrict__ acc, const int32_t *__restrict__ part, uint32_t shift, uint64_t count) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) acc[i] += (int32_t)((uint32_t)part[i] << shift);
+}
+
+static int ensure_weight_planes(impop_ctx *ctx, const impop_matrix *m) {
+    if (m->d_wplanes) return IMPOP_OK;
+    const uint64_t n_dword = 2 * m->g.n_block;
+    uint32_t *d_used = nullptr;
+    HIP_TRY(hipMalloc((void **)&m->d_wplanes, 32ull * n_dword * 4 + 256));
+    d_used = m->d_wplanes + 32ull * n_dword;
+    HIP_TRY(hipMemsetAsync(d_used, 0, 4, ctx->stream));
+    hipLaunchKernelGGL(weight_planes_kernel, dim3((uint32_t)((n_dword + 127) / 128)), dim3(128), 0, ctx->stream, m->d_wt, m->g.n_site,
+                       n_dword, 32u, m->d_wplanes, d_used);
+    HIP_TRY(hipGetLastError());
+    uint32_t used = 0;
+    HIP_TRY(hipMemcpyAsync(&used, d_used, 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    m->wplane_bits = used;
+    m->wplane_stride = n_dword;
+    if (!m->d_rb_masked) HIP_TRY(hipMalloc((void **)&m->d_rb_masked, m->rb_bytes));
+    return IMPOP_OK;
+}
+
+// Gram matrices of `n_win` cells (host copy h_wins of d_wins for the cell range) into d_out; d_tmp: a second buffer
+// of the same size, used by weighted matrices only
+static int launch_gram_any(impop_ctx *ctx, const impop_matrix *m, const GramWindow *d_wins, const GramWindow *h_wins,
+                           uint32_t n_win, int32_t *d_out, int32_t *d_tmp, uint64_t max_window_sites) {
+    if (m->wt_prefix.empty()) return launch_gram(ctx, m, m->d_rb, d_wins, n_win, d_out, max_window_sites);
+    int rc = ensure_weight_planes(ctx, m);
+    if (rc) return rc;
+    uint64_t c_lo = ~0ull, c_hi = 0;
+    for (uint32_t i = 0; i < n_win; ++i)
+        if (h_wins[i].site_end > h_wins[i].site_begin) {
+            c_lo = std::min(c_lo, h_wins[i].site_begin >> 6);
+            c_hi = std::max(c_hi, (h_wins[i].site_end + 63) >> 6);
+        }
+    const uint64_t count = (uint64_t)n_win * m->n_hap_pad * m->n_hap_pad;
+    HIP_TRY(hipMemsetAsync(d_out, 0, count * 4, ctx->stream));
+    if (c_lo >= c_hi) return IMPOP_OK;
+    c_hi = std::min<uint64_t>(c_hi + 8, m->rb_nb);  // the Gram pipeline prefetches a few cells past a window's end
+    const uint32_t n_group = m->n_hap_pad / 32;
+    const uint64_t threads = (c_hi - c_lo) * 32 * n_group;
+    REQUIRE((threads + 255) / 256 < 0x7FFFFFFFull && (count + 255) / 256 < 0x7FFFFFFFull, "weighted Gram: batch too large");
+    for (uint32_t k = 0; k < 32; ++k) {
+        if (!((m->wplane_bits >> k) & 1u)) continue;
+        hipLaunchKernelGGL(rb_mask_kernel, dim3((uint32_t)((threads + 255) / 256)), dim3(256), 0, ctx->stream, m->d_rb, m->d_rb_masked,
+                           m->rb_nb, n_group, c_lo, c_hi, m->d_wplanes + (uint64_t)k * m->wplane_stride, m->wplane_stride);
+        HIP_TRY(hipGetLastError());
+        rc = launch_gram(ctx, m, m->d_rb_masked, d_wins, n_win, d_tmp, max_window_sites);
+        if (rc) return rc;
+        hipLaunchKernelGGL(gram_accumulate_kernel, dim3((uint32_t)((count + 255) / 256)), dim3(256), 0, ctx->stream, d_out, d_tmp, k, count);
+        HIP_TRY(hipGetLastError());
+    }
+    return IMPOP_OK;
+}
+
+// ---- S for the all-pairs path from a cached site bitmap -----------------------------------------------------------
+// S = #{s in window : 0 < c_s < n} (all haplotypes: run_tajd.sh:126,148 take S from the un-subset graph).  Whether a
+// site segregates does not depend on the window, so it is computed ONCE per matrix — one streaming pass over the
+// SB64 layout, one bit per site — and kept with the matrix; a window's S is then a popcount over W / 8 bytes
+// instead of a second pass over its n W / 8 bytes behind every Gram launch (that pass was 1.83 ms of every
+// 12 ms batch of 4096 windows; the first call on a matrix still pays it once).
+typedef uint32_t u32q __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void segmap_kernel(const uint32_t *__restrict__ sb, uint32_t wps, uint32_t G, uint32_t r, uint32_t n,
+                                                     uint64_t n_block, uint32_t *__restrict__ out) {
+    const uint32_t lane = threadIdx.x & 63;
+    const uint64_t b = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= n_block) return;  // wave-uniform
+    const uint32_t *blk = sb + b * 64ull * wps;
+    uint32_t c = 0;
+    for (uint32_t g = 0; g + 1 < G; ++g) {
+        const u32q v = __builtin_nontemporal_load(reinterpret_cast<const u32q *>(blk + (uint64_t)g * 256 + lane * 4));
+        c += __popc(v.x) + __popc(v.y) + __popc(v.z) + __popc(v.w);
+    }
+    for (uint32_t e = 0; e < r; ++e) c += __popc(__builtin_nontemporal_load(blk + (uint64_t)(G - 1) * 256 + lane * r + e));
+    const uint64_t bal = __ballot((c - 1u) < (n - 1u));  // padding sites of the last block are all-zero: not segregating
+    if (lane == 0) { out[2 * b] = (uint32_t)bal; out[2 * b + 1] = (uint32_t)(bal >> 32); }
+}
+
+// one wave per window: popcount of the bitmap over [site_begin, site_end) -> s_all and s_p of the window's record
+__global__ __launch_bounds__(256) void seg_count_kernel(const uint32_t *__restrict__ map, const GramWindow *__restrict__ wins,
+                                                        uint64_t n_win, impop_window_stats *__restrict__ stats) {
+    const uint32_t lane = threadIdx.x & 63;
+    const uint64_t w = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (w >= n_win) return;
+    const uint64_t s0 = wins[w].site_begin, s1 = wins[w].site_end;
+    const uint64_t d0 = s0 >> 5, d1 = (s1 + 31) >> 5;
+    uint32_t cnt = 0;
+    for (uint64_t d = d0 + lane; d < d1; d += 64) {
+        uint32_t v = map[d];
+        if (d == d0) v &= 0xFFFFFFFFu << (s0 & 31);
+        if (d == d1 - 1 && (s1 & 31)) v &= 0xFFFFFFFFu >> (32 - (s1 & 31));
+        cnt += __popc(v);
+    }
+    cnt = wave_sum_u32(cnt);
+    if (lane == 0) { stats[w].s_all = cnt; stats[w].s_p = cnt; }
+}
+
+static int ensure_segmap(impop_ctx *ctx, const impop_matrix *m) {
+    if (m->d_segmap || m->g.n_block == 0) return IMPOP_OK;
+    HIP_TRY(hipMalloc((void **)&m->d_segmap, m->g.n_block * 8 + 256));
+    REQUIRE((m->g.n_block + 3) / 4 < 0x7FFFFFFFull, "site bitmap: matrix too long for one launch");
+    hipLaunchKernelGGL(segmap_kernel, dim3((uint32_t)((m->g.n_block + 3) / 4)), dim3(256), 0, ctx->stream, m->d_sb, m->g.wps, m->g.G,
+                       m->g.r, m->g.n_hap, m->g.n_block, m->d_segmap);
+    HIP_TRY(hipGetLastError());
+    return IMPOP_OK;
+}
+
+// W of a window: its length, or the sum of its columns' weights
+static inline uint64_t window_W(const impop_matrix *m, uint64_t s0, uint64_t s1) {
+    return m->wt_prefix.empty() ? s1 - s0 : m->wt_prefix[s1] - m->wt_prefix[s0];
 }
 
 struct Carve2 {
@@ -631,11 +793,10 @@ using namespace impop;
 static int check_pairwise_args(impop_ctx *ctx, const impop_matrix *m, uint64_t s0, uint64_t s1, const char *fn) {
     REQUIRE(ctx && m, "%s: NULL argument", fn);
     NOT_COMPACT(m, fn);
-    NOT_WEIGHTED(m, fn);
     REQUIRE(m->d_rb, "%s: matrix was created without IMPOP_KEEP_HAP_MAJOR", fn);
     REQUIRE(s0 <= s1 && s1 <= m->g.n_site, "%s: bad site range [%llu,%llu)", fn, (unsigned long long)s0,
             (unsigned long long)s1);
-    REQUIRE(s1 - s0 < (1ull << 31), "%s: window longer than 2^31 sites overflows int32 counts", fn);
+    REQUIRE(window_W(m, s0, s1) < (1ull << 31), "%s: window of 2^31 or more sites (or summed site weights) overflows int32 counts", fn);
     return IMPOP_OK;
 }
 
@@ -647,14 +808,15 @@ IMPOP_API int impop_pairwise_counts(impop_ctx *ctx, const impop_matrix *m, uint6
     HIP_TRY(hipSetDevice(ctx->device));
     const uint32_t n = m->g.n_hap, ld = m->n_hap_pad;
     void *d = nullptr;
-    rc = ctx_scratch(ctx, 512 + (size_t)ld * ld * 4, &d);
+    rc = ctx_scratch(ctx, 1024 + (size_t)ld * ld * 8, &d);
     if (rc) return rc;
     Carve2 cv(d);
     GramWindow *d_w = cv.take<GramWindow>(1);
     int32_t *d_g = cv.take<int32_t>((size_t)ld * ld);
+    int32_t *d_t = cv.take<int32_t>((size_t)ld * ld);
     GramWindow w{site_begin, site_end};
     HIP_TRY(hipMemcpyAsync(d_w, &w, sizeof w, hipMemcpyHostToDevice, ctx->stream));
-    rc = launch_gram(ctx, m, d_w, 1, d_g, site_end - site_begin);
+    rc = launch_gram_any(ctx, m, d_w, &w, 1, d_g, d_t, site_end - site_begin);
     if (rc) return rc;
     hipLaunchKernelGGL(gram_symmetrize_kernel, dim3((ld + 15) / 16, (ld + 15) / 16), dim3(16, 16), 0, ctx->stream, d_g, ld);
     HIP_TRY(hipGetLastError());
@@ -674,18 +836,19 @@ IMPOP_API int impop_pairwise_identity(impop_ctx *ctx, const impop_matrix *m, uin
     HIP_TRY(hipSetDevice(ctx->device));
     const uint32_t n = m->g.n_hap, ld = m->n_hap_pad;
     void *d = nullptr;
-    rc = ctx_scratch(ctx, 1024 + (size_t)ld * ld * 4 + (size_t)n * n * 8, &d);
+    rc = ctx_scratch(ctx, 2048 + (size_t)ld * ld * 8 + (size_t)n * n * 8, &d);
     if (rc) return rc;
     Carve2 cv(d);
     GramWindow *d_w = cv.take<GramWindow>(1);
     uint64_t *d_W = cv.take<uint64_t>(1);
     int32_t *d_g = cv.take<int32_t>((size_t)ld * ld);
+    int32_t *d_t = cv.take<int32_t>((size_t)ld * ld);
     double *d_id = cv.take<double>((size_t)n * n);
     GramWindow w{site_begin, site_end};
-    const uint64_t W = site_end - site_begin;
+    const uint64_t W = window_W(m, site_begin, site_end);
     HIP_TRY(hipMemcpyAsync(d_w, &w, sizeof w, hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(hipMemcpyAsync(d_W, &W, 8, hipMemcpyHostToDevice, ctx->stream));
-    rc = launch_gram(ctx, m, d_w, 1, d_g, site_end - site_begin);
+    rc = launch_gram_any(ctx, m, d_w, &w, 1, d_g, d_t, site_end - site_begin);
     if (rc) return rc;
     SimBatch b{};
     b.gram = d_g; b.stride = (uint64_t)ld * ld; b.ld = ld; b.n = n; b.W = d_W; b.kind = identity_kind; b.round_digits = -1;
@@ -701,7 +864,6 @@ IMPOP_API int impop_pairwise_scan(impop_ctx *ctx, const impop_matrix *m, const i
                                   const impop_pairwise_params *params, impop_pairwise_stats *out_host) {
     REQUIRE(ctx && m && params, "impop_pairwise_scan: NULL argument");
     NOT_COMPACT(m, "impop_pairwise_scan");
-    NOT_WEIGHTED(m, "impop_pairwise_scan");
     REQUIRE(params->struct_size == sizeof(impop_pairwise_params), "impop_pairwise_params.struct_size mismatch");
     REQUIRE(m->d_rb, "impop_pairwise_scan: matrix was created without IMPOP_KEEP_HAP_MAJOR");
     REQUIRE(params->identity_kind == IMPOP_IDENTITY_MATCH || params->identity_kind == IMPOP_IDENTITY_DICE,
@@ -724,9 +886,16 @@ IMPOP_API int impop_pairwise_scan(impop_ctx *ctx, const impop_matrix *m, const i
     // s_scope 2: the caller does not need S / Tajima's D (pica2- or Fst-only output): skip the site scan
     const bool want_s = params->s_scope != 2;
     if (!want_s) sp.s_scope = 0;
+    // without a subset mask S comes from the matrix's cached site bitmap (s_p = s_all); with one, s_p needs the
+    // subset's own counts: the streaming scan of the same windows
+    const bool use_segmap = want_s && !mask_p;
     impop_scan_plan *plan = nullptr;
-    int rc = want_s ? impop_scan_plan_create(ctx, m, windows, n_windows, mask_p, mask_a, mask_b, &sp, &plan) : IMPOP_OK;
+    int rc = (want_s && !use_segmap) ? impop_scan_plan_create(ctx, m, windows, n_windows, mask_p, mask_a, mask_b, &sp, &plan) : IMPOP_OK;
     if (rc) return rc;
+    if (use_segmap) {
+        rc = ensure_segmap(ctx, m);
+        if (rc) return rc;
+    }
     auto fail = [&](int code) {
         if (plan) impop_scan_plan_destroy(plan);
         return code;
@@ -813,18 +982,20 @@ IMPOP_API int impop_pairwise_scan(impop_ctx *ctx, const impop_matrix *m, const i
     }
     // Chunks of consecutive (in `ord`) windows whose cells fit the Gram scratch (<= ~4 GiB of 288): large
     // chunks keep the persistent Gram grid's last, partially filled round of tasks small next to the launch
+    const bool weighted = !m->wt_prefix.empty();
     const size_t gram_bytes = (size_t)ld * ld * 4;
-    uint64_t cap = (4ull << 30) / gram_bytes;
+    uint64_t cap = ((weighted ? 2ull : 4ull) << 30) / gram_bytes;  // weighted: a second Gram buffer for the plane partials
     if (cap < 1) cap = 1;
     if (cap > 4096) cap = 4096;
     void *d = nullptr;
-    const size_t need = 4096 + cap * (gram_bytes + sizeof(GramWindow) + 24 + sizeof(Pica2Out) + sizeof(HfstOut) +
-                                      sizeof(impop_window_stats) + sizeof(impop_pairwise_stats) + 2560) +
+    const size_t need = 4096 + cap * ((weighted ? 2 : 1) * gram_bytes + sizeof(GramWindow) + 24 + sizeof(Pica2Out) + sizeof(HfstOut) +
+                                      sizeof(impop_window_stats) + sizeof(impop_pairwise_stats) + sizeof(GramWindow) + 2560) +
                         (size_t)n * 16 + 8192;
     rc = ctx_scratch(ctx, need, &d);
     if (rc) return fail(rc);
     Carve2 cv(d);
     int32_t *d_g = cv.take<int32_t>(cap * (size_t)ld * ld);
+    int32_t *d_gt = weighted ? cv.take<int32_t>(cap * (size_t)ld * ld) : nullptr;
     GramWindow *d_w = cv.take<GramWindow>(cap);
     uint64_t *d_W = cv.take<uint64_t>(cap);
     uint64_t *d_L = cv.take<uint64_t>(cap);
@@ -834,6 +1005,7 @@ IMPOP_API int impop_pairwise_scan(impop_ctx *ctx, const impop_matrix *m, const i
     HfstOut *d_h = cv.take<HfstOut>(cap);
     impop_window_stats *d_s = cv.take<impop_window_stats>(cap);
     impop_pairwise_stats *d_o = cv.take<impop_pairwise_stats>(cap);
+    GramWindow *d_sw = cv.take<GramWindow>(cap);  // the chunk's WINDOWS (d_w holds its Gram cells)
     uint32_t *d_idx = cv.take<uint32_t>(n ? n : 1);
     uint8_t *d_fa = cv.take<uint8_t>(n ? n : 1);
     uint8_t *d_fb = cv.take<uint8_t>(n ? n : 1);
@@ -848,14 +1020,14 @@ IMPOP_API int impop_pairwise_scan(impop_ctx *ctx, const impop_matrix *m, const i
     if (!ia.empty()) PW_TRY(hipMemcpyAsync(d_ia, ia.data(), ia.size() * 4, hipMemcpyHostToDevice, ctx->stream));
     if (!ib.empty()) PW_TRY(hipMemcpyAsync(d_ib, ib.data(), ib.size() * 4, hipMemcpyHostToDevice, ctx->stream));
     std::vector<impop_window_stats> scan_host(n_windows);
-    if (want_s) {
+    if (plan) {
         rc = impop_scan_plan_launch(plan, nullptr);
         if (rc) return fail(rc);
         rc = impop_scan_plan_fetch(plan, scan_host.data());
         if (rc) return fail(rc);
-    } else {
+    } else {  // no S wanted, or S from the site bitmap (filled in on the device per chunk)
         memset(scan_host.data(), 0, n_windows * sizeof(impop_window_stats));
-        for (uint64_t i = 0; i < n_windows; ++i) scan_host[i].n_sites = (uint32_t)(windows[i].site_end - windows[i].site_begin);
+        for (uint64_t i = 0; i < n_windows; ++i) scan_host[i].n_sites = (uint32_t)window_W(m, windows[i].site_begin, windows[i].site_end);
     }
     // even out the chunks: a total slightly above the capacity would otherwise leave a last chunk of a few
     // windows whose single-workgroup epilogue kernels cost their full latency
@@ -867,7 +1039,7 @@ IMPOP_API int impop_pairwise_scan(impop_ctx *ctx, const impop_matrix *m, const i
         if ((cells.size() + n_chunks - 1) / n_chunks + widest > cap) ++n_chunks;  // neighbours re-contract up to `widest` cells
         cell_limit = std::min<uint64_t>(cap, (cells.size() + n_chunks - 1) / n_chunks + widest);
     }
-    std::vector<GramWindow> gw(cap);
+    std::vector<GramWindow> gw(cap), swv(cap);
     std::vector<uint64_t> Wv(cap), Lv(cap);
     std::vector<uint32_t> fv(cap), cvv(cap);
     std::vector<impop_window_stats> sv(cap);
@@ -902,11 +1074,12 @@ IMPOP_API int impop_pairwise_scan(impop_ctx *ctx, const impop_matrix *m, const i
         }
         for (uint64_t k = 0; k < cnt; ++k) {
             const uint64_t wdx = ord[base + k];
-            Wv[k] = windows[wdx].site_end - windows[wdx].site_begin;
+            Wv[k] = window_W(m, windows[wdx].site_begin, windows[wdx].site_end);
             Lv[k] = windows[wdx].seq_len;
             fv[k] = count[wdx] ? first[wdx] - c_lo : 0;
             cvv[k] = count[wdx];
             sv[k] = scan_host[wdx];
+            swv[k] = {windows[wdx].site_begin, windows[wdx].site_end};
         }
         if (n_cells) PW_TRY(hipMemcpyAsync(d_w, gw.data(), n_cells * sizeof(GramWindow), hipMemcpyHostToDevice, ctx->stream));
         PW_TRY(hipMemcpyAsync(d_W, Wv.data(), cnt * 8, hipMemcpyHostToDevice, ctx->stream));
@@ -914,22 +1087,43 @@ IMPOP_API int impop_pairwise_scan(impop_ctx *ctx, const impop_matrix *m, const i
         PW_TRY(hipMemcpyAsync(d_first, fv.data(), cnt * 4, hipMemcpyHostToDevice, ctx->stream));
         PW_TRY(hipMemcpyAsync(d_count, cvv.data(), cnt * 4, hipMemcpyHostToDevice, ctx->stream));
         PW_TRY(hipMemcpyAsync(d_s, sv.data(), cnt * sizeof(impop_window_stats), hipMemcpyHostToDevice, ctx->stream));
+        if (use_segmap) {
+            PW_TRY(hipMemcpyAsync(d_sw, swv.data(), cnt * sizeof(GramWindow), hipMemcpyHostToDevice, ctx->stream));
+            hipLaunchKernelGGL(seg_count_kernel, dim3((uint32_t)((cnt + 3) / 4)), dim3(256), 0, ctx->stream, m->d_segmap, d_sw, cnt, d_s);
+            PW_TRY(hipGetLastError());
+        }
         if (n_cells) {
-            rc = launch_gram(ctx, m, d_w, n_cells, d_g, max_sites);
+            rc = launch_gram_any(ctx, m, d_w, gw.data(), n_cells, d_g, d_gt, max_sites);
             if (rc) return fail(rc);
         }
         SimBatch b{};
         b.gram = d_g; b.stride = (uint64_t)ld * ld; b.ld = ld; b.n = n; b.W = d_W; b.kind = params->identity_kind;
         b.round_digits = params->round_digits < 0 ? -1 : params->round_digits;
         b.seg_first = d_first; b.seg_count = d_count;
-        rc = launch_pica2(ctx, b, cnt, mask_p ? d_idx : nullptr, nP, nullptr, params->threshold, d_L, d_p, nullptr);
-        if (rc) return fail(rc);
+        // pica2 grouping and the Fst sums are independent, latency-bound one-workgroup-per-window kernels: pica2 goes
+        // to the side stream (fork behind the Gram launch, join before the finalize) so the two overlap
+        {
+            if (!ctx->side) {
+                PW_TRY(hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking));
+                PW_TRY(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+                PW_TRY(hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
+            }
+            PW_TRY(hipEventRecord(ctx->ev_fork, ctx->stream));
+            PW_TRY(hipStreamWaitEvent(ctx->side, ctx->ev_fork, 0));
+            hipStream_t main_stream = ctx->stream;
+            ctx->stream = ctx->side;
+            rc = launch_pica2(ctx, b, cnt, mask_p ? d_idx : nullptr, nP, nullptr, params->threshold, d_L, d_p, nullptr);
+            ctx->stream = main_stream;
+            if (rc) return fail(rc);
+            PW_TRY(hipEventRecord(ctx->ev_join, ctx->side));
+        }
         if (params->fst_method == 1)
             rc = launch_hud_grouped(ctx, b, cnt, d_ia, (uint32_t)ia.size(), d_ib, (uint32_t)ib.size(), nullptr, nullptr, params->threshold,
                                         d_L, d_h);
         else
             rc = launch_hfst(ctx, b, cnt, d_fa, d_fb, d_L, d_h);
         if (rc) return fail(rc);
+        PW_TRY(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
         PairFinalIn in{d_p, d_h, d_s};
         rc = ensure_tajima_consts(ctx, nP >= 2 ? (int64_t)nP : 2);  // the cache may have been retargeted by another plan
         if (rc) return fail(rc);

@@ -251,11 +251,14 @@ __global__ __launch_bounds__(256, 4) void scan_tiles_anyn_kernel(const uint32_t 
     const ScanTile t = tiles[blockIdx.x];
     const uint64_t b0 = t.site_begin >> 6, b1 = (t.site_end + 63) >> 6;
     const uint32_t lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint32_t Gf = G - 1;  // full 16-byte granules; the last granule holds r = 1..4 dwords per site
+    // full 16-byte granules: all of them when the last one holds 4 dwords per site (r == 4: its addressing is
+    // the full granules'), else all but the last, whose r = 1..3 dwords per site are read one by one
+    const uint32_t Gf = r == 4 ? G : G - 1;
     LaneAcc acc;
     for (uint64_t b = b0 + wave; b < b1; b += 4) {
         const uint32_t *blk = sb + b * 64ull * wps + lane * 4;
         uint32_t c = 0, cP = 0, cA = 0, cB = 0;
+        // full batches of AN_U granules (all loads out first, consumed with staggered waits) ...
         uint32_t g = 0;
         for (; g + AN_U <= Gf; g += AN_U) {
             u32v4 v[AN_U];
@@ -264,13 +267,31 @@ __global__ __launch_bounds__(256, 4) void scan_tiles_anyn_kernel(const uint32_t 
 #pragma unroll
             for (int u = 0; u < AN_U; ++u) anyn_granule<SUBSET_P>(v[u], lp, la, lb, g + u, c, cP, cA, cB);
         }
-        for (; g < Gf; ++g)
-            anyn_granule<SUBSET_P>(stream_load(reinterpret_cast<const u32v4 *>(blk + (uint64_t)g * 256)), lp, la, lb, g, c, cP, cA, cB);
-        const uint32_t *last = sb + b * 64ull * wps + (uint64_t)Gf * 256 + lane * r;
-        for (uint32_t e = 0; e < r; ++e) {
-            const uint32_t v = stream_load(last + e), k = 4 * Gf + e;
-            c += __popc(v); cA += __popc(v & la[k]); cB += __popc(v & lb[k]);
-            if (SUBSET_P) cP += __popc(v & lp[k]);
+        // ... and ONE short batch for what is left (wave-uniform predicates): its loads still go out together; a
+        // one-at-a-time remainder loop paid the full HBM latency per granule
+        if (g < Gf) {
+            const uint32_t nb = Gf - g;
+            u32v4 v[AN_U];
+#pragma unroll
+            for (int u = 0; u < AN_U - 1; ++u)
+                if ((uint32_t)u < nb) v[u] = stream_load(reinterpret_cast<const u32v4 *>(blk + (uint64_t)(g + u) * 256));
+#pragma unroll
+            for (int u = 0; u < AN_U - 1; ++u)
+                if ((uint32_t)u < nb) anyn_granule<SUBSET_P>(v[u], lp, la, lb, g + u, c, cP, cA, cB);
+        }
+        if (Gf < G) {
+            const uint32_t *last = sb + b * 64ull * wps + (uint64_t)Gf * 256 + lane * r;
+            uint32_t tail[3] = {0u, 0u, 0u};
+#pragma unroll
+            for (int e = 0; e < 3; ++e)
+                if ((uint32_t)e < r) tail[e] = stream_load(last + e);
+#pragma unroll
+            for (int e = 0; e < 3; ++e)
+                if ((uint32_t)e < r) {
+                    const uint32_t v = tail[e], k = 4 * Gf + e;
+                    c += __popc(v); cA += __popc(v & la[k]); cB += __popc(v & lb[k]);
+                    if (SUBSET_P) cP += __popc(v & lp[k]);
+                }
         }
         if (!SUBSET_P) cP = c;
         const uint64_t s = b * 64 + lane;

@@ -171,6 +171,7 @@ __global__ __launch_bounds__(ST) void pica2_kernel(SimBatch batch, const uint32_
 // n (8 workgroups per CU) 0.15 us; issuing the loads of 8-32 column chunks ahead of their use did not help
 // (more registers, fewer waves).  Identities of pairs further apart than the memo reaches are computed
 // directly.
+typedef int i32v4 __attribute__((ext_vector_type(4)));
 constexpr uint32_t HF_LDS_N = 4096;  // problems up to this many sequences keep class + Gram diagonal in LDS
 __global__ __launch_bounds__(ST) void hfst_kernel(SimBatch batch, const uint8_t *__restrict__ in_a,
                                                   const uint8_t *__restrict__ in_b, const uint64_t *__restrict__ seq_len,
@@ -201,18 +202,42 @@ __global__ __launch_bounds__(ST) void hfst_kernel(SimBatch batch, const uint8_t 
     double accA = 0.0, accB = 0.0, accX = 0.0;
     uint64_t cA = 0, mA = 0, cB = 0, mB = 0, cX = 0, mX = 0;
     const uint32_t lane = tid & 63;
+    auto tally = [&](uint32_t cr, uint32_t cc, double s) {
+        const bool miss = s != s;
+        const double d = 1 - s;
+        if (cr != cc) { if (miss) ++mX; else { accX += d; ++cX; } }
+        else if (cr == 1) { if (miss) ++mA; else { accA += d; ++cA; } }
+        else { if (miss) ++mB; else { accB += d; ++cB; } }
+    };
     for (uint32_t r = tid >> 6; r < n; r += ST / 64) {
         const uint32_t cr = cached ? cls_l[r] : cls_of(r);  // wave-uniform
         if (!cr) continue;
+        if (S.gram && cached && (S.ld & 3u) == 0) {
+            // Gram rows, four columns per lane and step (one 16-byte load per segment): the kernel is a chain of
+            // dependent-latency steps at full occupancy, so fewer, wider loads is what shortens it
+            const int64_t ar = S.diag[r];
+            for (uint32_t c4 = ((r + 1) & ~3u) + 4 * lane; c4 < n; c4 += 256) {
+                const int32_t *g = S.gram + (uint64_t)r * S.ld + c4;
+                int64_t I[4] = {0, 0, 0, 0};
+                for (uint32_t k = 0; k < S.nseg; ++k) {
+                    const i32v4 v = *reinterpret_cast<const i32v4 *>(g + k * S.seg_stride);
+                    I[0] += v.x; I[1] += v.y; I[2] += v.z; I[3] += v.w;
+                }
+#pragma unroll
+                for (uint32_t e = 0; e < 4; ++e) {
+                    const uint32_t c = c4 + e;
+                    if (c <= r || c >= n) continue;
+                    const uint32_t cc = cls_l[c];
+                    if (!cc) continue;
+                    tally(cr, cc, sim_from_gram(S, I[e], ar, S.diag[c]));
+                }
+            }
+            continue;
+        }
         for (uint32_t c = r + 1 + lane; c < n; c += 64) {
             const uint32_t cc = cached ? cls_l[c] : cls_of(c);
             if (!cc) continue;
-            const double s = sim_get(S, r, c);
-            const bool miss = s != s;
-            const double d = 1 - s;
-            if (cr != cc) { if (miss) ++mX; else { accX += d; ++cX; } }
-            else if (cr == 1) { if (miss) ++mA; else { accA += d; ++cA; } }
-            else { if (miss) ++mB; else { accB += d; ++cB; } }
+            tally(cr, cc, sim_get(S, r, c));
         }
     }
     accA = block_sum_f64(accA, shd); accB = block_sum_f64(accB, shd); accX = block_sum_f64(accX, shd);

@@ -101,8 +101,10 @@ int impop_matrix_download(impop_ctx *ctx, const impop_matrix *m, uint64_t site_b
  * records of the bp-expanded matrix — while s_all / s_p / s_a / s_b keep counting COLUMNS (variable nodes,
  * what a VCF of the window lists, run_tajd.sh:148).  impop_matrix_compact keeps the weights (a window's W stays
  * the sum over all its original columns); impop_scan_multi honours them too.  Set them before building plans
- * (refused while plans of this matrix are alive).  The all-pairs path refuses weighted matrices
- * (IMPOP_E_UNSUPPORTED). */
+ * (refused while plans of this matrix are alive).  The all-pairs path (impop_pairwise_*) honours them as well:
+ * I_ij = sum_s w_s b_is b_js — the bp-weighted node-sharing counts behind `impg similarity`'s identity
+ * (run_pica2_impg.sh:162-175) — W = sum_s w_s, computed exactly through the weights' bit planes
+ * (I = sum_k 2^k Gram(M & W_k)); a window's summed weights must stay below 2^31. */
 int impop_matrix_set_site_weights(impop_ctx *ctx, impop_matrix *m, const uint32_t *weights_host);
 
 /* Keep only the sites that are variable among ALL haplotypes (0 < c_s < n), with their original

@@ -1070,3 +1070,95 @@ def test_weighted_window_beyond_u32_is_refused_and_afs_batches(ctx):
     assert afs.shape == (W, n + 1) and (afs.sum(axis=1) == 1).all()
     assert (afs[np.arange(W), c] == 1).all()
     bm.free()
+
+
+def test_weighted_gram_equals_bp_expanded_matrix(ctx, oracle):
+    """The all-pairs path on a NODE-level matrix with node lengths as site weights (what `impg similarity` hands the
+    reference is a bp-weighted node-sharing identity, run_pica2_impg.sh:162-175): I_ij = sum_s w_s b_is b_js through
+    the weights' bit planes must equal, bit for bit, the Gram matrix of the bp-expanded matrix — and with it the
+    identities and the thresholded pica2 / h-fst / grouped-Fst records of the real Tajima pipeline (-t 0.999 -r 5)."""
+    rng = np.random.default_rng(23)
+    for n, K, wmax in ((61, 700, 40), (465, 400, 300), (130, 260, 70000)):
+        founders = (rng.random((5, K)) < 0.5).astype(np.uint8)
+        nodes = founders[rng.integers(0, 5, size=n)] ^ (rng.random((n, K)) < 0.01).astype(np.uint8)
+        nodes[:, rng.random(K) < 0.3] = 1
+        length = rng.integers(1, wmax, size=K).astype(np.uint32)
+        if wmax > 65536:
+            length[rng.random(K) < 0.9] = 1  # a few very long nodes: 17 bit planes, most of them sparse
+        cum = np.concatenate(([0], np.cumsum(length))).astype(np.int64)
+        bn = ctx.upload_dense(nodes, keep_hap_major=True)
+        bn.set_site_weights(length)
+        wn = [(0, K), (3, K - 70), (K // 2, K // 2 + 1), (17, 17), (K - 130, K)]
+        expanded = np.repeat(nodes, length, axis=1) if cum[-1] < 200_000 else None
+        be = ctx.upload_dense(expanded, keep_hap_major=True) if expanded is not None else None
+        for a, b in wn:
+            I = bn.pairwise_counts(a, b)
+            nb = nodes[:, a:b].astype(np.int64)
+            want = (nb * length[a:b].astype(np.int64)) @ nb.T
+            assert (I.astype(np.int64) == want).all(), (n, a, b)
+            if be is not None:
+                assert (I == be.pairwise_counts(int(cum[a]), int(cum[b]))).all()
+                for kind in ("match", "dice"):
+                    assert bn.pairwise_identity(a, b, kind).tobytes() == be.pairwise_identity(int(cum[a]), int(cum[b]), kind).tobytes()
+        if be is not None:
+            inA = (rng.random(n) < 0.4).astype(np.uint8); inB = (rng.random(n) < 0.4).astype(np.uint8)
+            inP = (rng.random(n) < 0.8).astype(np.uint8)
+            wins_n = [(a, b, int(cum[b] - cum[a]) or 1) for a, b in wn] + [(0, K // 2, 777), (K // 4, K, 12345)]  # overlapping
+            wins_e = [(int(cum[a]), int(cum[b]), L) for a, b, L in wins_n]
+            for kind in ("match", "dice"):
+                for thr, rd, meth in ((0.999, 5, "direct"), (0.99, None, "direct"), (0.995, 3, "grouped")):
+                    for mp in (None, inP):
+                        got = bn.pairwise_scan(wins_n, mp, inA, inB, kind=kind, threshold=thr, round_digits=rd, s_scope=2, fst_method=meth)
+                        ref = be.pairwise_scan(wins_e, mp, inA, inB, kind=kind, threshold=thr, round_digits=rd, s_scope=2, fst_method=meth)
+                        assert got.tobytes() == ref.tobytes(), (n, kind, thr, rd, meth)
+            # with S: node-level S counts variable NODES (DESIGN §8-8); everything else equals the expanded matrix
+            got = bn.pairwise_scan(wins_n, None, inA, inB, kind="dice", threshold=0.999, round_digits=5, d_pi_mode=1)
+            ref = be.pairwise_scan(wins_e, None, inA, inB, kind="dice", threshold=0.999, round_digits=5, d_pi_mode=1)
+            for k in ("pi", "pi_site", "fst", "pi_a", "pi_b", "pi_xy", "dxy", "da", "n_groups", "n_sites"):
+                assert ((got[k] == ref[k]) | ((got[k] != got[k]) & (ref[k] != ref[k]))).all(), k
+            c = nodes.sum(axis=0)
+            for (a, b, L), r in zip(wins_n, got):
+                assert int(r["s_all"]) == int(((c[a:b] > 0) & (c[a:b] < n)).sum())
+            be.free()
+        bn.free()
+    # a window whose weights reach 2^31 cannot be held in the int32 Gram: refused, not wrapped
+    import impop_amd
+    big = ctx.upload_dense(np.ones((4, 40), np.uint8), keep_hap_major=True)
+    big.set_site_weights(np.full(40, 60_000_000, dtype=np.uint32))
+    with pytest.raises(impop_amd.ImpopError):
+        big.pairwise_counts(0, 40)
+    assert int(big.pairwise_counts(0, 30)[0, 0]) == 30 * 60_000_000
+    big.free()
+
+
+def test_config5_full_size_gram_and_scan_properties(ctx):
+    """BASELINE config 5 at FULL size — 4096 haplotypes x 10^7 sites (5.12 GB) resident, ONE window — on both paths,
+    through properties that need no oracle: the K-split FP4 Gram matrix is symmetric, reproducible byte for byte,
+    additive over a split of the site axis, has the row popcounts a_i on its diagonal, satisfies the checksum of
+    checksums  sum_ij I_ij = sum_s c_s^2  and, on sampled rows,  sum_j I_ij = sum_s b_is c_s  (c_s from
+    impop_site_counts); the streaming scan's integer sums equal sum_s c_s (n - c_s) and #{0 < c_s < n}."""
+    n, W = 4096, 10_000_000
+    bm = ctx.synthetic(n, W, seed=5, n_founder=16, p_founder=0.05, p_private_word=0.05, keep_hap_major=True)
+    I = bm.pairwise_counts(0, W)
+    assert bm.pairwise_counts(0, W).tobytes() == I.tobytes()
+    assert (I == I.T).all()
+    c = bm.site_counts(0, W).astype(np.int64)
+    assert int(I.astype(np.int64).sum()) == int((c * c).sum())
+    cut = 4_321_987
+    assert (I == bm.pairwise_counts(0, cut) + bm.pairwise_counts(cut, W)).all()
+    bits = bm.download(0, W)                                     # [4096, 156250] uint64
+    assert (np.diag(I).astype(np.int64) == np.bitwise_count(bits).sum(axis=1, dtype=np.int64)).all()
+    for i in (0, 1, 31, 32, 2047, 2048, 4095):
+        b = np.unpackbits(bits[i].view(np.uint8), bitorder="little")[:W]
+        assert int(I[i].astype(np.int64).sum()) == int(c[b.astype(bool)].sum()), i
+    del bits
+    r = bm.scan([(0, W, W)])[0]
+    assert int(r["n_sites"]) == W and int(r["sum_p"]) == int((c * (n - c)).sum())
+    assert int(r["s_all"]) == int(((c > 0) & (c < n)).sum())
+    # the same window through the all-pairs statistics: pica2 at threshold >= 1 is the site-count pi
+    p = bm.pairwise_scan([(0, W, W)], None, np.arange(n) < 1000, np.arange(n) >= 3000, kind="match", threshold=1.0)[0]
+    s = bm.scan([(0, W, W)], None, np.arange(n) < 1000, np.arange(n) >= 3000)[0]
+    for k in ("pi", "pi_site", "fst", "pi_a", "pi_b", "dxy", "tajima_d"):
+        assert rel_close(float(p[k]), float(s[k]), REL, 1e-300), (k, float(p[k]), float(s[k]))
+    assert int(p["s_all"]) == int(s["s_all"]) and int(p["n_sites"]) == W
+    bm.free()

@@ -121,6 +121,10 @@ struct impop_matrix {
     // lazily built bitmap of the sites that segregate among ALL haplotypes (bit s of dword s>>5), cached for the
     // all-pairs path's S (pairwise.hip); dropped with the matrix
     mutable uint32_t *d_segmap = nullptr;
+    // compacted matrix built from one that kept its hap-major copy: bitmap, in ORIGINAL site coordinates, of the
+    // dropped sites that EVERY haplotype carries (c_s = n): each adds 1 to every I_ij, so the all-pairs path on the
+    // variable sites alone plus this per-window count is exact (pairwise.hip)
+    uint32_t *d_onesmap = nullptr;
     bool compact = false;
     uint64_t n_site_orig = 0;
     std::vector<uint64_t> pos;

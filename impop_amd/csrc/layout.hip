@@ -346,7 +346,8 @@ namespace impop {
 // grid-stride over blocks: a workgroup per 4 blocks cost more in launches than in bytes (37 ms for 14.6 GB)
 __global__ __launch_bounds__(256) void variable_mask_kernel(const uint32_t *__restrict__ sb, uint32_t wps, uint32_t G,
                                                             uint32_t r, uint64_t n_block, uint64_t n_site, uint32_t n_hap,
-                                                            uint64_t *__restrict__ mask, uint32_t *__restrict__ cnt) {
+                                                            uint64_t *__restrict__ mask, uint32_t *__restrict__ cnt,
+                                                            uint64_t *__restrict__ ones /* nullable: sites with c = n */) {
     const uint32_t lane = threadIdx.x & 63;
     const uint64_t stride = (uint64_t)gridDim.x * 4;
     for (uint64_t b = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6); b < n_block; b += stride) {
@@ -359,7 +360,11 @@ __global__ __launch_bounds__(256) void variable_mask_kernel(const uint32_t *__re
         for (uint32_t j = 0; j < r; ++j) c += __popc(site[(uint64_t)(G - 1) * 256 + lane * r + j]);
         const bool var = (b * 64 + lane < n_site) && c > 0 && c < n_hap;
         const uint64_t m = __ballot(var);
-        if (lane == 0) { mask[b] = m; cnt[b] = (uint32_t)__popcll(m); }
+        const uint64_t o = ones ? __ballot((b * 64 + lane < n_site) && c == n_hap) : 0ull;
+        if (lane == 0) {
+            mask[b] = m; cnt[b] = (uint32_t)__popcll(m);
+            if (ones) ones[b] = o;
+        }
     }
 }
 
@@ -448,10 +453,16 @@ IMPOP_API int impop_matrix_compact(impop_ctx *ctx, const impop_matrix *in, impop
              *d_chunk = (uint64_t *)((char *)d + o_chunk), *d_total = (uint64_t *)((char *)d + o_total);
     uint32_t *d_cnt = (uint32_t *)((char *)d + o_cnt);
     uint64_t n_kept = 0;
+    // a source that kept its hap-major copy hands the all-pairs path on: the compacted matrix gets its own RB32
+    // operand and the bitmap of the dropped all-ones sites (not for weighted sources: their dropped columns would
+    // each add their own weight)
+    const bool want_pairs = in->d_rb != nullptr && in->wt_prefix.empty();
+    uint64_t *d_ones = nullptr;
+    if (want_pairs && nb) HIP_TRY(hipMalloc((void **)&d_ones, nb * 8 + 256));
     if (nb) {
         const uint32_t wide_grid = (uint32_t)std::min<uint64_t>((nb + 3) / 4, 32ull * (uint64_t)(ctx->n_cu > 0 ? ctx->n_cu : 256));
         hipLaunchKernelGGL(variable_mask_kernel, dim3(wide_grid), dim3(256), 0, ctx->stream, in->d_sb, g.wps, g.G, g.r, nb, g.n_site,
-                           g.n_hap, d_mask, d_cnt);
+                           g.n_hap, d_mask, d_cnt, d_ones);
         hipLaunchKernelGGL(chunk_sum_kernel, dim3((uint32_t)n_chunks), dim3(256), 0, ctx->stream, d_cnt, nb, d_chunk);
         hipLaunchKernelGGL(chunk_scan_kernel, dim3(1), dim3(64), 0, ctx->stream, d_chunk, n_chunks, d_total);
         hipLaunchKernelGGL(block_base_kernel, dim3((uint32_t)n_chunks), dim3(64), 0, ctx->stream, d_cnt, nb, d_chunk, d_base);
@@ -460,8 +471,12 @@ IMPOP_API int impop_matrix_compact(impop_ctx *ctx, const impop_matrix *in, impop
         HIP_TRY(hipStreamSynchronize(ctx->stream));
     }
     impop_matrix *m = nullptr;
-    rc = alloc_matrix(ctx, g.n_hap, n_kept, false, &m);
-    if (rc) return rc;
+    rc = alloc_matrix(ctx, g.n_hap, n_kept, want_pairs, &m);
+    if (rc) {
+        if (d_ones) hipFree(d_ones);
+        return rc;
+    }
+    m->d_onesmap = reinterpret_cast<uint32_t *>(d_ones);  // uint64 per 64-site block == two dwords of 32 sites
     auto fail = [&](int code) {
         impop_matrix_free(ctx, m);
         return code;
@@ -484,6 +499,10 @@ IMPOP_API int impop_matrix_compact(impop_ctx *ctx, const impop_matrix *in, impop
         if ((e = hipGetLastError()) != hipSuccess) return fail2(e, "gather_variable_kernel");
         if ((e = hipMemcpyAsync(m->pos.data(), d_pos, n_kept * 8, hipMemcpyDeviceToHost, ctx->stream)) != hipSuccess)
             return fail2(e, "hipMemcpyAsync(positions)");
+        if (want_pairs) {
+            const int rc2 = launch_sb_to_hm(ctx, m->d_sb, m->g, 0, m->g.n_block, m->d_rb, 0, m->n_hap_pad, m->rb_nb);
+            if (rc2) { hipFree(d_pos); return fail(rc2); }
+        }
         if ((e = hipStreamSynchronize(ctx->stream)) != hipSuccess) return fail2(e, "hipStreamSynchronize");
         hipFree(d_pos);
     }
@@ -568,6 +587,7 @@ IMPOP_API int impop_matrix_free(impop_ctx *ctx, impop_matrix *m) {
     if (m->d_sb) hipFree(m->d_sb);
     if (m->d_rb) hipFree(m->d_rb);
     if (m->d_wt) hipFree(m->d_wt);
+    if (m->d_onesmap) hipFree(m->d_onesmap);
     matrix_drop_derived(m);
     delete m;
     return IMPOP_OK;

@@ -741,7 +741,8 @@ __global__ __launch_bounds__(256) void segmap_kernel(const uint32_t *__restrict_
 
 // one wave per window: popcount of the bitmap over [site_begin, site_end) -> s_all and s_p of the window's record
 __global__ __launch_bounds__(256) void seg_count_kernel(const uint32_t *__restrict__ map, const GramWindow *__restrict__ wins,
-                                                        uint64_t n_win, impop_window_stats *__restrict__ stats) {
+                                                        uint64_t n_win, impop_window_stats *__restrict__ stats /* nullable */,
+                                                        uint32_t *__restrict__ plain /* nullable: one count per window */) {
     const uint32_t lane = threadIdx.x & 63;
     const uint64_t w = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (w >= n_win) return;
@@ -755,7 +756,23 @@ __global__ __launch_bounds__(256) void seg_count_kernel(const uint32_t *__restri
         cnt += __popc(v);
     }
     cnt = wave_sum_u32(cnt);
-    if (lane == 0) { stats[w].s_all = cnt; stats[w].s_p = cnt; }
+    if (lane == 0) {
+        if (stats) { stats[w].s_all = cnt; stats[w].s_p = cnt; }
+        if (plain) plain[w] = cnt;
+    }
+}
+
+// compacted matrix: the dropped all-ones sites of [site_begin, site_end) (ORIGINAL coordinates) add 1 to every I_ij
+__global__ void gram_add_const_kernel(int32_t *__restrict__ g, uint32_t ld, uint32_t n, const uint32_t *__restrict__ add) {
+    const uint32_t i = blockIdx.y * blockDim.y + threadIdx.y, j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && j < n) g[(uint64_t)i * ld + j] += (int32_t)add[0];
+}
+
+// kept-site index range of an original-coordinate range on a compacted matrix (identity otherwise)
+static inline void map_range(const impop_matrix *m, uint64_t s0, uint64_t s1, uint64_t *k0, uint64_t *k1) {
+    if (!m->compact) { *k0 = s0; *k1 = s1; return; }
+    *k0 = (uint64_t)(std::lower_bound(m->pos.begin(), m->pos.end(), s0) - m->pos.begin());
+    *k1 = (uint64_t)(std::lower_bound(m->pos.begin(), m->pos.end(), s1) - m->pos.begin());
 }
 
 static int ensure_segmap(impop_ctx *ctx, const impop_matrix *m) {
@@ -792,9 +809,13 @@ using namespace impop;
 
 static int check_pairwise_args(impop_ctx *ctx, const impop_matrix *m, uint64_t s0, uint64_t s1, const char *fn) {
     REQUIRE(ctx && m, "%s: NULL argument", fn);
-    NOT_COMPACT(m, fn);
+    if (m->compact && !(m->d_rb && m->d_onesmap)) {
+        set_error("%s: this compacted matrix has no all-pairs operand (compact a matrix that kept IMPOP_KEEP_HAP_MAJOR and has no "
+                  "site weights)", fn);
+        return IMPOP_E_UNSUPPORTED;
+    }
     REQUIRE(m->d_rb, "%s: matrix was created without IMPOP_KEEP_HAP_MAJOR", fn);
-    REQUIRE(s0 <= s1 && s1 <= m->g.n_site, "%s: bad site range [%llu,%llu)", fn, (unsigned long long)s0,
+    REQUIRE(s0 <= s1 && s1 <= matrix_span(m), "%s: bad site range [%llu,%llu)", fn, (unsigned long long)s0,
             (unsigned long long)s1);
     REQUIRE(window_W(m, s0, s1) < (1ull << 31), "%s: window of 2^31 or more sites (or summed site weights) overflows int32 counts", fn);
     return IMPOP_OK;
@@ -808,16 +829,26 @@ IMPOP_API int impop_pairwise_counts(impop_ctx *ctx, const impop_matrix *m, uint6
     HIP_TRY(hipSetDevice(ctx->device));
     const uint32_t n = m->g.n_hap, ld = m->n_hap_pad;
     void *d = nullptr;
-    rc = ctx_scratch(ctx, 1024 + (size_t)ld * ld * 8, &d);
+    rc = ctx_scratch(ctx, 2048 + (size_t)ld * ld * 8, &d);
     if (rc) return rc;
     Carve2 cv(d);
     GramWindow *d_w = cv.take<GramWindow>(1);
     int32_t *d_g = cv.take<int32_t>((size_t)ld * ld);
     int32_t *d_t = cv.take<int32_t>((size_t)ld * ld);
-    GramWindow w{site_begin, site_end};
+    GramWindow *d_ow = cv.take<GramWindow>(1);
+    uint32_t *d_add = cv.take<uint32_t>(1);
+    GramWindow w;
+    map_range(m, site_begin, site_end, &w.site_begin, &w.site_end);  // compacted: the kept sites of the range
     HIP_TRY(hipMemcpyAsync(d_w, &w, sizeof w, hipMemcpyHostToDevice, ctx->stream));
-    rc = launch_gram_any(ctx, m, d_w, &w, 1, d_g, d_t, site_end - site_begin);
+    rc = launch_gram_any(ctx, m, d_w, &w, 1, d_g, d_t, w.site_end - w.site_begin);
     if (rc) return rc;
+    const GramWindow ow{site_begin, site_end};
+    if (m->compact) {  // + the dropped sites every haplotype carries
+        HIP_TRY(hipMemcpyAsync(d_ow, &ow, sizeof ow, hipMemcpyHostToDevice, ctx->stream));
+        hipLaunchKernelGGL(seg_count_kernel, dim3(1), dim3(256), 0, ctx->stream, m->d_onesmap, d_ow, 1, (impop_window_stats *)nullptr, d_add);
+        hipLaunchKernelGGL(gram_add_const_kernel, dim3((n + 15) / 16, (n + 15) / 16), dim3(16, 16), 0, ctx->stream, d_g, ld, n, d_add);
+        HIP_TRY(hipGetLastError());
+    }
     hipLaunchKernelGGL(gram_symmetrize_kernel, dim3((ld + 15) / 16, (ld + 15) / 16), dim3(16, 16), 0, ctx->stream, d_g, ld);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpy2DAsync(out_host, (size_t)n * 4, d_g, (size_t)ld * 4, (size_t)n * 4, n, hipMemcpyDeviceToHost,
@@ -836,7 +867,7 @@ IMPOP_API int impop_pairwise_identity(impop_ctx *ctx, const impop_matrix *m, uin
     HIP_TRY(hipSetDevice(ctx->device));
     const uint32_t n = m->g.n_hap, ld = m->n_hap_pad;
     void *d = nullptr;
-    rc = ctx_scratch(ctx, 2048 + (size_t)ld * ld * 8 + (size_t)n * n * 8, &d);
+    rc = ctx_scratch(ctx, 4096 + (size_t)ld * ld * 8 + (size_t)n * n * 8, &d);
     if (rc) return rc;
     Carve2 cv(d);
     GramWindow *d_w = cv.take<GramWindow>(1);
@@ -844,14 +875,24 @@ IMPOP_API int impop_pairwise_identity(impop_ctx *ctx, const impop_matrix *m, uin
     int32_t *d_g = cv.take<int32_t>((size_t)ld * ld);
     int32_t *d_t = cv.take<int32_t>((size_t)ld * ld);
     double *d_id = cv.take<double>((size_t)n * n);
-    GramWindow w{site_begin, site_end};
-    const uint64_t W = window_W(m, site_begin, site_end);
+    GramWindow *d_ow = cv.take<GramWindow>(1);
+    uint32_t *d_add = cv.take<uint32_t>(1);
+    GramWindow w;
+    map_range(m, site_begin, site_end, &w.site_begin, &w.site_end);
+    const uint64_t W = window_W(m, site_begin, site_end);  // the window's ORIGINAL length
     HIP_TRY(hipMemcpyAsync(d_w, &w, sizeof w, hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(hipMemcpyAsync(d_W, &W, 8, hipMemcpyHostToDevice, ctx->stream));
-    rc = launch_gram_any(ctx, m, d_w, &w, 1, d_g, d_t, site_end - site_begin);
+    rc = launch_gram_any(ctx, m, d_w, &w, 1, d_g, d_t, w.site_end - w.site_begin);
     if (rc) return rc;
     SimBatch b{};
     b.gram = d_g; b.stride = (uint64_t)ld * ld; b.ld = ld; b.n = n; b.W = d_W; b.kind = identity_kind; b.round_digits = -1;
+    const GramWindow ow{site_begin, site_end};
+    if (m->compact) {
+        HIP_TRY(hipMemcpyAsync(d_ow, &ow, sizeof ow, hipMemcpyHostToDevice, ctx->stream));
+        hipLaunchKernelGGL(seg_count_kernel, dim3(1), dim3(256), 0, ctx->stream, m->d_onesmap, d_ow, 1, (impop_window_stats *)nullptr, d_add);
+        HIP_TRY(hipGetLastError());
+        b.add = d_add;
+    }
     hipLaunchKernelGGL(identity_dense_kernel, dim3((n + 15) / 16, (n + 15) / 16), dim3(16, 16), 0, ctx->stream, b, n, d_id);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(out_host, d_id, (size_t)n * n * 8, hipMemcpyDeviceToHost, ctx->stream));
@@ -863,9 +904,7 @@ IMPOP_API int impop_pairwise_scan(impop_ctx *ctx, const impop_matrix *m, const i
                                   const uint64_t *mask_p, const uint64_t *mask_a, const uint64_t *mask_b,
                                   const impop_pairwise_params *params, impop_pairwise_stats *out_host) {
     REQUIRE(ctx && m && params, "impop_pairwise_scan: NULL argument");
-    NOT_COMPACT(m, "impop_pairwise_scan");
     REQUIRE(params->struct_size == sizeof(impop_pairwise_params), "impop_pairwise_params.struct_size mismatch");
-    REQUIRE(m->d_rb, "impop_pairwise_scan: matrix was created without IMPOP_KEEP_HAP_MAJOR");
     REQUIRE(params->identity_kind == IMPOP_IDENTITY_MATCH || params->identity_kind == IMPOP_IDENTITY_DICE,
             "impop_pairwise_scan: unknown identity kind");
     REQUIRE(params->round_digits <= 19, "impop_pairwise_scan: round_digits > 19 unsupported");
@@ -920,6 +959,10 @@ IMPOP_API int impop_pairwise_scan(impop_ctx *ctx, const impop_matrix *m, const i
     // contracted once however many windows cover it, and a window is the sum of its consecutive segments
     // (formed on the fly by the statistics kernels, SimBatch.seg_*).  Without overlap the cells are the
     // windows themselves.
+    // compacted matrix: the contraction runs over the KEPT (variable) sites of each window; the dropped all-ones
+    // sites come back as a per-window constant (SimBatch.add), the dropped all-zero sites contribute nothing
+    std::vector<impop_window> mw;
+    map_windows(m, windows, n_windows, mw);
     struct Cell { uint64_t b, e; };
     std::vector<Cell> cells;                                // all Gram cells, in site order when segmented
     std::vector<uint32_t> first(n_windows, 0), count(n_windows, 0);
@@ -929,19 +972,19 @@ IMPOP_API int impop_pairwise_scan(impop_ctx *ctx, const impop_matrix *m, const i
         std::vector<uint64_t> cuts;
         uint64_t win_sites = 0;
         for (uint64_t i = 0; i < n_windows; ++i)
-            if (windows[i].site_end > windows[i].site_begin) {
-                cuts.push_back(windows[i].site_begin);
-                cuts.push_back(windows[i].site_end);
-                win_sites += windows[i].site_end - windows[i].site_begin;
+            if (mw[i].site_end > mw[i].site_begin) {
+                cuts.push_back(mw[i].site_begin);
+                cuts.push_back(mw[i].site_end);
+                win_sites += mw[i].site_end - mw[i].site_begin;
             }
         std::sort(cuts.begin(), cuts.end());
         cuts.erase(std::unique(cuts.begin(), cuts.end()), cuts.end());
         auto at = [&](uint64_t s) { return (size_t)(std::lower_bound(cuts.begin(), cuts.end(), s) - cuts.begin()); };
         std::vector<int64_t> cover(cuts.size() + 1, 0);
         for (uint64_t i = 0; i < n_windows; ++i)
-            if (windows[i].site_end > windows[i].site_begin) {
-                cover[at(windows[i].site_begin)] += 1;
-                cover[at(windows[i].site_end)] -= 1;
+            if (mw[i].site_end > mw[i].site_begin) {
+                cover[at(mw[i].site_begin)] += 1;
+                cover[at(mw[i].site_end)] -= 1;
             }
         std::vector<uint32_t> seg_before(cuts.size() + 1, 0);  // covered intervals left of cut k
         uint64_t seg_sites = 0;
@@ -959,9 +1002,9 @@ IMPOP_API int impop_pairwise_scan(impop_ctx *ctx, const impop_matrix *m, const i
         if (seg_sites * 20 < win_sites * 19 && segs.size() < 0xFFFFFFF0ull) {  // >= 5 % of the contraction is shared
             cells.swap(segs);
             for (uint64_t i = 0; i < n_windows; ++i)
-                if (windows[i].site_end > windows[i].site_begin) {
-                    first[i] = seg_before[at(windows[i].site_begin)];
-                    count[i] = seg_before[at(windows[i].site_end)] - first[i];
+                if (mw[i].site_end > mw[i].site_begin) {
+                    first[i] = seg_before[at(mw[i].site_begin)];
+                    count[i] = seg_before[at(mw[i].site_end)] - first[i];
                 }
             std::stable_sort(ord.begin(), ord.end(), [&](uint64_t a, uint64_t b) {
                 const bool ea = count[a] == 0, eb = count[b] == 0;  // empty windows last
@@ -974,7 +1017,7 @@ IMPOP_API int impop_pairwise_scan(impop_ctx *ctx, const impop_matrix *m, const i
             }
             cells.resize(n_windows);
             for (uint64_t i = 0; i < n_windows; ++i) {
-                cells[i] = {windows[i].site_begin, windows[i].site_end};
+                cells[i] = {mw[i].site_begin, mw[i].site_end};
                 first[i] = (uint32_t)i;
                 count[i] = 1;
             }
@@ -989,7 +1032,7 @@ IMPOP_API int impop_pairwise_scan(impop_ctx *ctx, const impop_matrix *m, const i
     if (cap > 4096) cap = 4096;
     void *d = nullptr;
     const size_t need = 4096 + cap * ((weighted ? 2 : 1) * gram_bytes + sizeof(GramWindow) + 24 + sizeof(Pica2Out) + sizeof(HfstOut) +
-                                      sizeof(impop_window_stats) + sizeof(impop_pairwise_stats) + sizeof(GramWindow) + 2560) +
+                                      sizeof(impop_window_stats) + sizeof(impop_pairwise_stats) + 2 * sizeof(GramWindow) + 4 + 3584) +
                         (size_t)n * 16 + 8192;
     rc = ctx_scratch(ctx, need, &d);
     if (rc) return fail(rc);
@@ -1005,7 +1048,9 @@ IMPOP_API int impop_pairwise_scan(impop_ctx *ctx, const impop_matrix *m, const i
     HfstOut *d_h = cv.take<HfstOut>(cap);
     impop_window_stats *d_s = cv.take<impop_window_stats>(cap);
     impop_pairwise_stats *d_o = cv.take<impop_pairwise_stats>(cap);
-    GramWindow *d_sw = cv.take<GramWindow>(cap);  // the chunk's WINDOWS (d_w holds its Gram cells)
+    GramWindow *d_sw = cv.take<GramWindow>(cap);  // the chunk's WINDOWS (d_w holds its Gram cells), matrix coordinates
+    GramWindow *d_ow = cv.take<GramWindow>(cap);  // the same windows in ORIGINAL coordinates (compacted matrices)
+    uint32_t *d_add = cv.take<uint32_t>(cap);     // compacted: dropped all-ones sites per window
     uint32_t *d_idx = cv.take<uint32_t>(n ? n : 1);
     uint8_t *d_fa = cv.take<uint8_t>(n ? n : 1);
     uint8_t *d_fb = cv.take<uint8_t>(n ? n : 1);
@@ -1039,7 +1084,7 @@ IMPOP_API int impop_pairwise_scan(impop_ctx *ctx, const impop_matrix *m, const i
         if ((cells.size() + n_chunks - 1) / n_chunks + widest > cap) ++n_chunks;  // neighbours re-contract up to `widest` cells
         cell_limit = std::min<uint64_t>(cap, (cells.size() + n_chunks - 1) / n_chunks + widest);
     }
-    std::vector<GramWindow> gw(cap), swv(cap);
+    std::vector<GramWindow> gw(cap), swv(cap), owv(cap);
     std::vector<uint64_t> Wv(cap), Lv(cap);
     std::vector<uint32_t> fv(cap), cvv(cap);
     std::vector<impop_window_stats> sv(cap);
@@ -1079,7 +1124,8 @@ IMPOP_API int impop_pairwise_scan(impop_ctx *ctx, const impop_matrix *m, const i
             fv[k] = count[wdx] ? first[wdx] - c_lo : 0;
             cvv[k] = count[wdx];
             sv[k] = scan_host[wdx];
-            swv[k] = {windows[wdx].site_begin, windows[wdx].site_end};
+            swv[k] = {mw[wdx].site_begin, mw[wdx].site_end};
+            owv[k] = {windows[wdx].site_begin, windows[wdx].site_end};
         }
         if (n_cells) PW_TRY(hipMemcpyAsync(d_w, gw.data(), n_cells * sizeof(GramWindow), hipMemcpyHostToDevice, ctx->stream));
         PW_TRY(hipMemcpyAsync(d_W, Wv.data(), cnt * 8, hipMemcpyHostToDevice, ctx->stream));
@@ -1089,7 +1135,8 @@ IMPOP_API int impop_pairwise_scan(impop_ctx *ctx, const impop_matrix *m, const i
         PW_TRY(hipMemcpyAsync(d_s, sv.data(), cnt * sizeof(impop_window_stats), hipMemcpyHostToDevice, ctx->stream));
         if (use_segmap) {
             PW_TRY(hipMemcpyAsync(d_sw, swv.data(), cnt * sizeof(GramWindow), hipMemcpyHostToDevice, ctx->stream));
-            hipLaunchKernelGGL(seg_count_kernel, dim3((uint32_t)((cnt + 3) / 4)), dim3(256), 0, ctx->stream, m->d_segmap, d_sw, cnt, d_s);
+            hipLaunchKernelGGL(seg_count_kernel, dim3((uint32_t)((cnt + 3) / 4)), dim3(256), 0, ctx->stream, m->d_segmap, d_sw, cnt, d_s,
+                               (uint32_t *)nullptr);
             PW_TRY(hipGetLastError());
         }
         if (n_cells) {
@@ -1100,6 +1147,13 @@ IMPOP_API int impop_pairwise_scan(impop_ctx *ctx, const impop_matrix *m, const i
         b.gram = d_g; b.stride = (uint64_t)ld * ld; b.ld = ld; b.n = n; b.W = d_W; b.kind = params->identity_kind;
         b.round_digits = params->round_digits < 0 ? -1 : params->round_digits;
         b.seg_first = d_first; b.seg_count = d_count;
+        if (m->compact) {
+            PW_TRY(hipMemcpyAsync(d_ow, owv.data(), cnt * sizeof(GramWindow), hipMemcpyHostToDevice, ctx->stream));
+            hipLaunchKernelGGL(seg_count_kernel, dim3((uint32_t)((cnt + 3) / 4)), dim3(256), 0, ctx->stream, m->d_onesmap, d_ow, cnt,
+                               (impop_window_stats *)nullptr, d_add);
+            PW_TRY(hipGetLastError());
+            b.add = d_add;
+        }
         // pica2 grouping and the Fst sums are independent, latency-bound one-workgroup-per-window kernels: pica2 goes
         // to the side stream (fork behind the Gram launch, join before the finalize) so the two overlap
         {

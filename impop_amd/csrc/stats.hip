@@ -112,9 +112,15 @@ __global__ __launch_bounds__(ST) void pica2_kernel(SimBatch batch, const uint32_
     __shared__ uint32_t sh_have;
     __shared__ uint64_t sh_npairs;
     const uint64_t prob = blockIdx.x;
-    const SimView S = sim_view(batch, prob);  // no identity memo here: with few groups it costs more than it saves
+    SimView S = sim_view(batch, prob);  // no identity memo here: with few groups it costs more than it saves
     const uint32_t tid = threadIdx.x;
     if (tid == 0) { sh_have = 0; sh_npairs = 0; }
+    if (S.gram) {  // Gram problems: the diagonal a_i in LDS (behind the other arrays), else every identity costs three loads
+        int32_t *diag_l = reinterpret_cast<int32_t *>(gsz + n_el);
+        for (uint32_t i = tid; i < batch.n; i += ST) diag_l[i] = (int32_t)gram_at(S, i, i);
+        S.diag = diag_l;
+        __syncthreads();
+    }
     // Step 1 (pica2.py:94-112)
     const uint32_t G = greedy_groups(S, idx, n_el, threshold, order, grp, gsz, rep, reinterpret_cast<uint32_t *>(rowsum));
     // Step 2-3 (pica2.py:118-154): sum over group pairs of 2*(1-sim(rep_i,rep_j))*f_i*f_j
@@ -176,7 +182,7 @@ constexpr uint32_t HF_LDS_N = 4096;  // problems up to this many sequences keep 
 __global__ __launch_bounds__(ST) void hfst_kernel(SimBatch batch, const uint8_t *__restrict__ in_a,
                                                   const uint8_t *__restrict__ in_b, const uint64_t *__restrict__ seq_len,
                                                   HfstOut *__restrict__ out) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char hf_lds[];  // diag[n] int32 | cls[n] u8 (n <= HF_LDS_N)
+    extern __shared__ __attribute__((aligned(16))) unsigned char hf_lds[];  // diag[n4] int32 | cls[n4] u8 | rows[n] u32 (n <= HF_LDS_N)
     __shared__ double shd[ST / 64];
     __shared__ uint64_t shu[ST / 64];
     __shared__ double sim_tbl[SIM_TBL_N];
@@ -186,15 +192,16 @@ __global__ __launch_bounds__(ST) void hfst_kernel(SimBatch batch, const uint8_t 
     const uint32_t n = batch.n, tid = threadIdx.x;
     const bool cached = n <= HF_LDS_N;
     int32_t *diag_l = reinterpret_cast<int32_t *>(hf_lds);
-    uint8_t *cls_l = hf_lds + (size_t)n * 4;
+    const uint32_t n4 = (n + 3) & ~3u;  // the Gram path reads classes / diagonal four at a time
+    uint8_t *cls_l = hf_lds + (size_t)n4 * 4;
     auto cls_of = [&](uint32_t i) -> uint32_t {  // 1 = A only, 2 = B only, 0 = neither or both (h-fst.py:181-185)
         const bool a = in_a[i], b = in_b[i];
         return (a && !b) ? 1u : (b && !a) ? 2u : 0u;
     };
     if (cached) {
-        for (uint32_t i = tid; i < n; i += ST) {
-            cls_l[i] = (uint8_t)cls_of(i);
-            if (S.gram) diag_l[i] = (int32_t)gram_at(S, i, i);
+        for (uint32_t i = tid; i < n4; i += ST) {
+            cls_l[i] = i < n ? (uint8_t)cls_of(i) : (uint8_t)0;
+            if (S.gram) diag_l[i] = i < n ? (int32_t)gram_at(S, i, i) : 0;
         }
         if (S.gram) S.diag = diag_l;
     }
@@ -209,31 +216,67 @@ __global__ __launch_bounds__(ST) void hfst_kernel(SimBatch batch, const uint8_t 
         else if (cr == 1) { if (miss) ++mA; else { accA += d; ++cA; } }
         else { if (miss) ++mB; else { accB += d; ++cB; } }
     };
-    for (uint32_t r = tid >> 6; r < n; r += ST / 64) {
-        const uint32_t cr = cached ? cls_l[r] : cls_of(r);  // wave-uniform
-        if (!cr) continue;
-        if (S.gram && cached && (S.ld & 3u) == 0) {
-            // Gram rows, four columns per lane and step (one 16-byte load per segment): the kernel is a chain of
-            // dependent-latency steps at full occupancy, so fewer, wider loads is what shortens it
+    if (S.gram && cached && (S.ld & 3u) == 0) {
+        // Gram problems (every pair present): member rows only, lanes own FIXED columns (4 per lane and 256-column
+        // step, one 16-byte load per segment), the row's class is wave-uniform and the column classes sit in a packed
+        // LDS word, so a pair costs a handful of branch-free instructions: Hamming distance -> memoised identity ->
+        // masked adds into (same class, other class).  Pair counts are the class sizes' products — nothing to count.
+        __shared__ uint32_t n_members, n_a, n_b;
+        uint32_t *rows_l = reinterpret_cast<uint32_t *>(hf_lds + (((size_t)n4 * 5 + 15) & ~(size_t)15));  // member rows, ascending
+        if (tid == 0) { n_members = 0; n_a = 0; n_b = 0; }
+        __syncthreads();
+        if (tid < 64) {  // one wave compacts the member list in order (ballot + prefix popcount)
+            uint32_t base = 0, na = 0, nb = 0;
+            for (uint32_t i0 = 0; i0 < n; i0 += 64) {
+                const uint32_t i = i0 + tid;
+                const uint32_t cc = i < n ? cls_l[i] : 0u;
+                const uint64_t bal = __ballot(cc != 0);
+                if (cc) rows_l[base + (uint32_t)__popcll(bal & ((1ull << tid) - 1ull))] = i;
+                base += (uint32_t)__popcll(bal);
+                na += (uint32_t)__popcll(__ballot(cc == 1));
+                nb += (uint32_t)__popcll(__ballot(cc == 2));
+            }
+            if (tid == 0) { n_members = base; n_a = na; n_b = nb; }
+        }
+        __syncthreads();
+        const uint32_t nm = n_members;
+        for (uint32_t k = tid >> 6; k < nm; k += ST / 64) {
+            const uint32_t r = rows_l[k];
+            const uint32_t cr = cls_l[r];
             const int64_t ar = S.diag[r];
-            for (uint32_t c4 = ((r + 1) & ~3u) + 4 * lane; c4 < n; c4 += 256) {
+            double same = 0.0, other = 0.0;
+            for (uint32_t c4 = 4 * lane; c4 < n; c4 += 256) {
+                if (c4 + 3 <= r) continue;  // entirely left of the diagonal
                 const int32_t *g = S.gram + (uint64_t)r * S.ld + c4;
-                int64_t I[4] = {0, 0, 0, 0};
-                for (uint32_t k = 0; k < S.nseg; ++k) {
-                    const i32v4 v = *reinterpret_cast<const i32v4 *>(g + k * S.seg_stride);
+                int64_t I[4] = {S.add, S.add, S.add, S.add};
+                for (uint32_t q = 0; q < S.nseg; ++q) {
+                    const i32v4 v = *reinterpret_cast<const i32v4 *>(g + q * S.seg_stride);
                     I[0] += v.x; I[1] += v.y; I[2] += v.z; I[3] += v.w;
                 }
+                const uint32_t cls4 = *reinterpret_cast<const uint32_t *>(cls_l + c4);  // n <= ld, LDS padded to 4
+                const i32v4 dg = *reinterpret_cast<const i32v4 *>(diag_l + c4);
+                const int32_t dgv[4] = {dg.x, dg.y, dg.z, dg.w};
 #pragma unroll
                 for (uint32_t e = 0; e < 4; ++e) {
                     const uint32_t c = c4 + e;
-                    if (c <= r || c >= n) continue;
-                    const uint32_t cc = cls_l[c];
-                    if (!cc) continue;
-                    tally(cr, cc, sim_from_gram(S, I[e], ar, S.diag[c]));
+                    const uint32_t cc = (cls4 >> (8 * e)) & 0xFFu;
+                    const bool live = (c > r) & (c < n) & (cc != 0);
+                    const double d = 1 - sim_from_gram(S, I[e], ar, (int64_t)dgv[e]);
+                    same += (live & (cc == cr)) ? d : 0.0;
+                    other += (live & (cc != cr)) ? d : 0.0;
                 }
             }
-            continue;
+            if (cr == 1) accA += same; else accB += same;
+            accX += other;
         }
+        if (tid == 0) {
+            const uint64_t na = n_a, nb = n_b;
+            cA = na * (na - (na ? 1 : 0)) / 2; cB = nb * (nb - (nb ? 1 : 0)) / 2; cX = na * nb;
+        }
+    } else
+    for (uint32_t r = tid >> 6; r < n; r += ST / 64) {
+        const uint32_t cr = cached ? cls_l[r] : cls_of(r);  // wave-uniform
+        if (!cr) continue;
         for (uint32_t c = r + 1 + lane; c < n; c += 64) {
             const uint32_t cc = cached ? cls_l[c] : cls_of(c);
             if (!cc) continue;
@@ -450,8 +493,8 @@ int launch_pica2(impop_ctx *ctx, const SimBatch &b, uint64_t n_problems, const u
                  const uint32_t *d_order, double threshold, const uint64_t *d_seq_len, Pica2Out *d_out,
                  uint32_t *d_group_of) {
     if (!n_problems) return IMPOP_OK;
-    const size_t lds = (size_t)n_el * (8 + 12) + 16;
-    REQUIRE(lds <= 150 * 1024, "pica2: %u elements exceed the LDS-resident grouping limit (7600)", n_el);
+    const size_t lds = (size_t)n_el * (8 + 12) + (b.gram ? (size_t)b.n * 4 : 0) + 16;
+    REQUIRE(lds <= 150 * 1024, "pica2: %u elements exceed the LDS-resident grouping limit (7600; 6300 on Gram problems)", n_el);
     REQUIRE(n_problems < 0x7FFFFFFFull, "pica2: too many problems");
     if (lds > 48 * 1024)
         HIP_TRY(hipFuncSetAttribute((const void *)pica2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -465,7 +508,9 @@ int launch_hfst(impop_ctx *ctx, const SimBatch &b, uint64_t n_problems, const ui
                 const uint64_t *d_seq_len, HfstOut *d_out) {
     if (!n_problems) return IMPOP_OK;
     REQUIRE(n_problems < 0x7FFFFFFFull, "hfst: too many problems");
-    const size_t lds = b.n <= HF_LDS_N ? (size_t)b.n * 5 + 16 : 16;
+    // diag[n4] int32 | cls[n4] u8 | (16-aligned) member rows[n] u32, n4 = n rounded up to 4
+    const size_t n4 = ((size_t)b.n + 3) & ~(size_t)3;
+    const size_t lds = b.n <= HF_LDS_N ? ((n4 * 5 + 15) & ~(size_t)15) + (size_t)b.n * 4 + 16 : 16;
     hipLaunchKernelGGL(hfst_kernel, dim3((uint32_t)n_problems), dim3(ST), lds, ctx->stream, b, d_in_a, d_in_b, d_seq_len,
                        d_out);
     HIP_TRY(hipGetLastError());

@@ -22,6 +22,9 @@ struct SimBatch {
     // nullptr = exactly one matrix per problem, at index p
     const uint32_t *seg_first;
     const uint32_t *seg_count;
+    // gram mode, optional: per-problem constant added to EVERY I_ij (diagonal included): the sites all haplotypes
+    // carry, which a compacted matrix dropped (pairwise.hip)
+    const uint32_t *add;
 };
 
 struct SimView {
@@ -39,6 +42,7 @@ struct SimView {
     const int32_t *diag;  // optional LDS copy of the Gram diagonal a_i (else read from `gram`)
     uint32_t nseg;        // Gram matrices to add up (gram mode)
     uint64_t seg_stride;  // elements between them
+    int64_t add;          // constant added to every Gram entry
 };
 
 constexpr uint32_t SIM_TBL_N = 1024;  // 8 KB: LDS footprint decides the occupancy of the epilogue kernels
@@ -78,13 +82,14 @@ __device__ inline SimView sim_view(const SimBatch &b, uint64_t p) {
     v.tbl = nullptr;
     v.tbl_n = 0;
     v.diag = nullptr;
+    v.add = (b.gram && b.add) ? (int64_t)b.add[p] : 0;
     return v;
 }
 
 // Gram entry (i, j) of a problem = sum over its segments
 __device__ inline int64_t gram_at(const SimView &S, uint32_t i, uint32_t j) {
     const int32_t *g = S.gram + (uint64_t)i * S.ld + j;
-    int64_t v = 0;
+    int64_t v = S.add;
     for (uint32_t k = 0; k < S.nseg; ++k) v += g[k * S.seg_stride];
     return v;
 }

@@ -80,7 +80,7 @@ def main():
     ap.add_argument("--fst-method", choices=["direct", "grouped"], default="direct",
                     help="hfst: grouped = scripts/hudson/hud.py -m grouped at -t (default 0.999), per window on the all-pairs path")
     ap.add_argument("--compact", action="store_true", help="scan from the matrix compacted to its variable sites "
-                    "(impop_matrix_compact): identical output, far fewer bytes per pass; not for thresholded pica2")
+                    "(impop_matrix_compact): identical output, far fewer bytes (and, on the all-pairs path, multiply-adds) per pass")
     ap.add_argument("--device", type=int, default=None, help="default: LOCAL_RANK, else 0")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend when launched with WORLD_SIZE > 1 "
                     "(nccl = RCCL over xGMI; gloo for rehearsals)")
@@ -136,8 +136,9 @@ def main():
         if mf.site_weight is not None:
             bm.set_site_weights(mf.site_weight)
     if args.compact:
-        if need_pairwise:
-            print("Error: --compact cannot be combined with thresholded / rounded pica2 (all-pairs path)", file=sys.stderr)
+        if need_pairwise and mf.site_weight is not None:
+            print("Error: --compact on a weighted (node-level) matrix cannot serve the all-pairs path (thresholded / rounded "
+                  "pica2, grouped Fst)", file=sys.stderr)
             sys.exit(2)
         full = bm
         bm = full.compact()

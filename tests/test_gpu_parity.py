@@ -567,8 +567,8 @@ def test_ehh_vs_reference_goldens_and_oracle(ctx, oracle):
 def test_compacted_matrix_gives_identical_records(ctx, oracle):
     """impop_matrix_compact keeps only the sites variable among all haplotypes; scans of it with the
     ORIGINAL windows must return byte-identical records (n_sites, integer sums, every double), for
-    subsets, overlapping / ragged / empty windows and the K-population scan.  Per-site and all-pairs
-    entry points refuse a compacted matrix."""
+    subsets, overlapping / ragged / empty windows and the K-population scan.  Per-site
+    entry points refuse a compacted matrix (the all-pairs path: test_all_pairs_path_on_compacted_matrix)."""
     import impop_amd
     from impop_amd import ImpopError
     rng = np.random.default_rng(11)
@@ -1162,3 +1162,43 @@ def test_config5_full_size_gram_and_scan_properties(ctx):
         assert rel_close(float(p[k]), float(s[k]), REL, 1e-300), (k, float(p[k]), float(s[k]))
     assert int(p["s_all"]) == int(s["s_all"]) and int(p["n_sites"]) == W
     bm.free()
+
+
+def test_all_pairs_path_on_compacted_matrix(ctx, oracle):
+    """impop_matrix_compact of a matrix that kept its hap-major copy serves the all-pairs path: the contraction runs
+    over the variable sites of a window only, every dropped site that all haplotypes carry comes back as +1 on every
+    I_ij.  Counts, identities (match and dice) and the thresholded pica2 / h-fst / grouped-Fst / D records must be
+    byte-identical to the full matrix's, windows given in ORIGINAL coordinates (overlapping ones too)."""
+    import impop_amd
+    rng = np.random.default_rng(31)
+    for n, W in ((61, 3000), (465, 20000), (700, 5000)):
+        anc = rng.integers(0, 2, size=W, dtype=np.uint8)                       # about half the sites are all-ones
+        f = np.repeat(anc[None], 6, axis=0) ^ (rng.random((6, W)) < 0.004).astype(np.uint8)
+        m = f[rng.integers(0, 6, size=n)] ^ (rng.random((n, W)) < 0.0005).astype(np.uint8)
+        full = ctx.upload_dense(m, keep_hap_major=True)
+        cm = full.compact()
+        assert 0 < cm.n_site < W // 4
+        c = m.sum(axis=0)
+        assert cm.n_site == int(((c > 0) & (c < n)).sum())
+        for a, b in ((0, W), (17, W - 33), (W // 2, W // 2 + 1), (100, 100), (W - 64, W)):
+            I = cm.pairwise_counts(a, b)
+            assert (I == full.pairwise_counts(a, b)).all(), (n, a, b)
+            mm = m[:, a:b].astype(np.int64)
+            assert (I.astype(np.int64) == mm @ mm.T).all()
+            for kind in ("match", "dice"):
+                assert cm.pairwise_identity(a, b, kind).tobytes() == full.pairwise_identity(a, b, kind).tobytes()
+        inA = (rng.random(n) < 0.4).astype(np.uint8); inB = (rng.random(n) < 0.4).astype(np.uint8)
+        inP = (rng.random(n) < 0.8).astype(np.uint8)
+        for wins in (impop_amd.fixed_windows(W, 1000), impop_amd.fixed_windows(W, 1500, 500), [(5, 5, 1), (0, W, 12345)]):
+            for kind, thr, rd, meth, mp in (("match", 0.999, 5, "direct", None), ("dice", 0.9995, None, "direct", inP),
+                                            ("match", 0.998, 4, "grouped", None), ("dice", 1.0, None, "direct", None)):
+                got = cm.pairwise_scan(wins, mp, inA, inB, kind=kind, threshold=thr, round_digits=rd, fst_method=meth)
+                ref = full.pairwise_scan(wins, mp, inA, inB, kind=kind, threshold=thr, round_digits=rd, fst_method=meth)
+                assert got.tobytes() == ref.tobytes(), (n, kind, thr, rd, meth)
+        cm.free(); full.free()
+    # a compacted matrix without the operand (source kept no hap-major copy) still refuses, loudly
+    src = ctx.upload_dense(m, keep_hap_major=False)
+    c2 = src.compact()
+    with pytest.raises(impop_amd.ImpopError):
+        c2.pairwise_counts(0, 10)
+    c2.free(); src.free()

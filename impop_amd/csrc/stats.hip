@@ -123,6 +123,14 @@ __global__ __launch_bounds__(ST) void pica2_kernel(SimBatch batch, const uint32_
     }
     // Step 1 (pica2.py:94-112)
     const uint32_t G = greedy_groups(S, idx, n_el, threshold, order, grp, gsz, rep, reinterpret_cast<uint32_t *>(rowsum));
+    // many groups: memoise the `match` identity by Hamming distance (same arithmetic, bit-identical values) — the
+    // G(G-1)/2 representative pairs then cost a table look-up each instead of a division and a decimal rounding;
+    // with few groups filling the table would cost more than it saves
+    __shared__ double sim_tbl[SIM_TBL_N];
+    if (G >= 48) {
+        sim_table_fill(S, sim_tbl, ST);
+        __syncthreads();
+    }
     // Step 2-3 (pica2.py:118-154): sum over group pairs of 2*(1-sim(rep_i,rep_j))*f_i*f_j
     const double total = (double)n_el;
     uint32_t have = 0;

@@ -1032,24 +1032,31 @@ IMPOP_API int impop_pairwise_scan(impop_ctx *ctx, const impop_matrix *m, const i
     if (cap > 4096) cap = 4096;
     void *d = nullptr;
     const size_t need = 4096 + cap * ((weighted ? 2 : 1) * gram_bytes + sizeof(GramWindow) + 24 + sizeof(Pica2Out) + sizeof(HfstOut) +
-                                      sizeof(impop_window_stats) + sizeof(impop_pairwise_stats) + 2 * sizeof(GramWindow) + 4 + 3584) +
+                                      sizeof(impop_window_stats) + sizeof(impop_pairwise_stats) + 2 * sizeof(GramWindow) + 4 + 3584) + 16 * 256 +
                         (size_t)n * 16 + 8192;
     rc = ctx_scratch(ctx, need, &d);
     if (rc) return fail(rc);
     Carve2 cv(d);
     int32_t *d_g = cv.take<int32_t>(cap * (size_t)ld * ld);
     int32_t *d_gt = weighted ? cv.take<int32_t>(cap * (size_t)ld * ld) : nullptr;
-    GramWindow *d_w = cv.take<GramWindow>(cap);
-    uint64_t *d_W = cv.take<uint64_t>(cap);
-    uint64_t *d_L = cv.take<uint64_t>(cap);
-    uint32_t *d_first = cv.take<uint32_t>(cap);
-    uint32_t *d_count = cv.take<uint32_t>(cap);
+    // per-chunk metadata: ONE contiguous region mirrored on the host, so that a chunk costs one host-to-device copy
+    // (eight small pageable copies were ~0.3 ms of host time between two Gram launches)
+    auto up256 = [](size_t x) { return (x + 255) / 256 * 256; };
+    const size_t o_w = 0, o_W = o_w + up256(cap * sizeof(GramWindow)), o_L = o_W + up256(cap * 8), o_first = o_L + up256(cap * 8),
+                 o_count = o_first + up256(cap * 4), o_s = o_count + up256(cap * 4), o_sw = o_s + up256(cap * sizeof(impop_window_stats)),
+                 o_ow = o_sw + up256(cap * sizeof(GramWindow)), meta_bytes = o_ow + up256(cap * sizeof(GramWindow));
+    char *d_meta = cv.take<char>(meta_bytes);
+    GramWindow *d_w = reinterpret_cast<GramWindow *>(d_meta + o_w);
+    uint64_t *d_W = reinterpret_cast<uint64_t *>(d_meta + o_W);
+    uint64_t *d_L = reinterpret_cast<uint64_t *>(d_meta + o_L);
+    uint32_t *d_first = reinterpret_cast<uint32_t *>(d_meta + o_first);
+    uint32_t *d_count = reinterpret_cast<uint32_t *>(d_meta + o_count);
     Pica2Out *d_p = cv.take<Pica2Out>(cap);
     HfstOut *d_h = cv.take<HfstOut>(cap);
-    impop_window_stats *d_s = cv.take<impop_window_stats>(cap);
+    impop_window_stats *d_s = reinterpret_cast<impop_window_stats *>(d_meta + o_s);
     impop_pairwise_stats *d_o = cv.take<impop_pairwise_stats>(cap);
-    GramWindow *d_sw = cv.take<GramWindow>(cap);  // the chunk's WINDOWS (d_w holds its Gram cells), matrix coordinates
-    GramWindow *d_ow = cv.take<GramWindow>(cap);  // the same windows in ORIGINAL coordinates (compacted matrices)
+    GramWindow *d_sw = reinterpret_cast<GramWindow *>(d_meta + o_sw);  // the chunk's WINDOWS (d_w holds its Gram cells), matrix coordinates
+    GramWindow *d_ow = reinterpret_cast<GramWindow *>(d_meta + o_ow);  // the same windows in ORIGINAL coordinates (compacted matrices)
     uint32_t *d_add = cv.take<uint32_t>(cap);     // compacted: dropped all-ones sites per window
     uint32_t *d_idx = cv.take<uint32_t>(n ? n : 1);
     uint8_t *d_fa = cv.take<uint8_t>(n ? n : 1);
@@ -1084,10 +1091,12 @@ IMPOP_API int impop_pairwise_scan(impop_ctx *ctx, const impop_matrix *m, const i
         if ((cells.size() + n_chunks - 1) / n_chunks + widest > cap) ++n_chunks;  // neighbours re-contract up to `widest` cells
         cell_limit = std::min<uint64_t>(cap, (cells.size() + n_chunks - 1) / n_chunks + widest);
     }
-    std::vector<GramWindow> gw(cap), swv(cap), owv(cap);
-    std::vector<uint64_t> Wv(cap), Lv(cap);
-    std::vector<uint32_t> fv(cap), cvv(cap);
-    std::vector<impop_window_stats> sv(cap);
+    std::vector<char> hmeta(meta_bytes, 0);
+    GramWindow *gw = reinterpret_cast<GramWindow *>(hmeta.data() + o_w), *swv = reinterpret_cast<GramWindow *>(hmeta.data() + o_sw),
+               *owv = reinterpret_cast<GramWindow *>(hmeta.data() + o_ow);
+    uint64_t *Wv = reinterpret_cast<uint64_t *>(hmeta.data() + o_W), *Lv = reinterpret_cast<uint64_t *>(hmeta.data() + o_L);
+    uint32_t *fv = reinterpret_cast<uint32_t *>(hmeta.data() + o_first), *cvv = reinterpret_cast<uint32_t *>(hmeta.data() + o_count);
+    impop_window_stats *sv = reinterpret_cast<impop_window_stats *>(hmeta.data() + o_s);
     std::vector<impop_pairwise_stats> ov(cap);
     for (uint64_t base = 0; base < n_windows;) {
         // windows ord[base .. base+cnt): their cells are [c_lo, c_hi)
@@ -1127,20 +1136,14 @@ IMPOP_API int impop_pairwise_scan(impop_ctx *ctx, const impop_matrix *m, const i
             swv[k] = {mw[wdx].site_begin, mw[wdx].site_end};
             owv[k] = {windows[wdx].site_begin, windows[wdx].site_end};
         }
-        if (n_cells) PW_TRY(hipMemcpyAsync(d_w, gw.data(), n_cells * sizeof(GramWindow), hipMemcpyHostToDevice, ctx->stream));
-        PW_TRY(hipMemcpyAsync(d_W, Wv.data(), cnt * 8, hipMemcpyHostToDevice, ctx->stream));
-        PW_TRY(hipMemcpyAsync(d_L, Lv.data(), cnt * 8, hipMemcpyHostToDevice, ctx->stream));
-        PW_TRY(hipMemcpyAsync(d_first, fv.data(), cnt * 4, hipMemcpyHostToDevice, ctx->stream));
-        PW_TRY(hipMemcpyAsync(d_count, cvv.data(), cnt * 4, hipMemcpyHostToDevice, ctx->stream));
-        PW_TRY(hipMemcpyAsync(d_s, sv.data(), cnt * sizeof(impop_window_stats), hipMemcpyHostToDevice, ctx->stream));
+        PW_TRY(hipMemcpyAsync(d_meta, hmeta.data(), meta_bytes, hipMemcpyHostToDevice, ctx->stream));
         if (use_segmap) {
-            PW_TRY(hipMemcpyAsync(d_sw, swv.data(), cnt * sizeof(GramWindow), hipMemcpyHostToDevice, ctx->stream));
             hipLaunchKernelGGL(seg_count_kernel, dim3((uint32_t)((cnt + 3) / 4)), dim3(256), 0, ctx->stream, m->d_segmap, d_sw, cnt, d_s,
                                (uint32_t *)nullptr);
             PW_TRY(hipGetLastError());
         }
         if (n_cells) {
-            rc = launch_gram_any(ctx, m, d_w, gw.data(), n_cells, d_g, d_gt, max_sites);
+            rc = launch_gram_any(ctx, m, d_w, gw, n_cells, d_g, d_gt, max_sites);
             if (rc) return fail(rc);
         }
         SimBatch b{};
@@ -1148,7 +1151,6 @@ IMPOP_API int impop_pairwise_scan(impop_ctx *ctx, const impop_matrix *m, const i
         b.round_digits = params->round_digits < 0 ? -1 : params->round_digits;
         b.seg_first = d_first; b.seg_count = d_count;
         if (m->compact) {
-            PW_TRY(hipMemcpyAsync(d_ow, owv.data(), cnt * sizeof(GramWindow), hipMemcpyHostToDevice, ctx->stream));
             hipLaunchKernelGGL(seg_count_kernel, dim3((uint32_t)((cnt + 3) / 4)), dim3(256), 0, ctx->stream, m->d_onesmap, d_ow, cnt,
                                (impop_window_stats *)nullptr, d_add);
             PW_TRY(hipGetLastError());
@@ -1156,7 +1158,11 @@ IMPOP_API int impop_pairwise_scan(impop_ctx *ctx, const impop_matrix *m, const i
         }
         // pica2 grouping and the Fst sums are independent, latency-bound one-workgroup-per-window kernels: pica2 goes
         // to the side stream (fork behind the Gram launch, join before the finalize) so the two overlap
-        {
+        static const bool use_side = [] { const char *e = getenv("IMPOP_PW_SIDE_STREAM"); return !(e && e[0] == '0'); }();
+        if (!use_side) {  // A/B switch (tools/): the two kernels one after the other on the main stream
+            rc = launch_pica2(ctx, b, cnt, mask_p ? d_idx : nullptr, nP, nullptr, params->threshold, d_L, d_p, nullptr);
+            if (rc) return fail(rc);
+        } else {
             if (!ctx->side) {
                 PW_TRY(hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking));
                 PW_TRY(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
@@ -1177,7 +1183,7 @@ IMPOP_API int impop_pairwise_scan(impop_ctx *ctx, const impop_matrix *m, const i
         else
             rc = launch_hfst(ctx, b, cnt, d_fa, d_fb, d_L, d_h);
         if (rc) return fail(rc);
-        PW_TRY(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
+        if (use_side) PW_TRY(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
         PairFinalIn in{d_p, d_h, d_s};
         rc = ensure_tajima_consts(ctx, nP >= 2 ? (int64_t)nP : 2);  // the cache may have been retargeted by another plan
         if (rc) return fail(rc);

@@ -269,7 +269,9 @@ __global__ __launch_bounds__(ST) void hfst_kernel(SimBatch batch, const uint8_t 
                     const uint32_t c = c4 + e;
                     const uint32_t cc = (cls4 >> (8 * e)) & 0xFFu;
                     const bool live = (c > r) & (c < n) & (cc != 0);
-                    const double d = 1 - sim_from_gram(S, I[e], ar, (int64_t)dgv[e]);
+                    // dead lanes (left of the diagonal, padding, non-members) get the all-zero pair: a memo hit, never
+                    // the division + decimal-rounding path the whole wave would have to wait for
+                    const double d = 1 - sim_from_gram(S, live ? I[e] : 0, live ? ar : 0, live ? (int64_t)dgv[e] : 0);
                     same += (live & (cc == cr)) ? d : 0.0;
                     other += (live & (cc != cr)) ? d : 0.0;
                 }

@@ -122,6 +122,7 @@ IMPOP_API int impop_ctx_destroy(impop_ctx *ctx) {
     if (ctx->d_taj) hipFree(ctx->d_taj);
     if (ctx->d_queue) hipFree(ctx->d_queue);
     if (ctx->scratch) hipFree(ctx->scratch);
+    if (ctx->d_part) hipFree(ctx->d_part);
     if (ctx->side) { hipStreamSynchronize(ctx->side); hipStreamDestroy(ctx->side); }
     if (ctx->ev_fork) hipEventDestroy(ctx->ev_fork);
     if (ctx->ev_join) hipEventDestroy(ctx->ev_join);

@@ -95,6 +95,8 @@ struct impop_ctx {
     // growable scratch
     void *scratch = nullptr;
     size_t scratch_bytes = 0;
+    void *d_part = nullptr;  // partial sums of split epilogue problems (stats.hip launch_hfst)
+    size_t part_bytes = 0;
 };
 
 struct impop_matrix {

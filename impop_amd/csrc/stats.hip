@@ -121,13 +121,19 @@ __global__ __launch_bounds__(ST) void pica2_kernel(SimBatch batch, const uint32_
         S.diag = diag_l;
         __syncthreads();
     }
+    // The `match` identity of a Gram problem is a function of the Hamming distance alone: memoise it (same arithmetic,
+    // bit-identical values) instead of a division + decimal rounding per evaluation.  Large problems fill the memo up
+    // front (the grouping itself makes up to n_el^2 / 2 evaluations), small ones only once they turn out to have many
+    // groups (with a handful of groups filling it costs more than it saves)
+    __shared__ double sim_tbl[SIM_TBL_N];
+    const bool memo_first = n_el >= 1024;
+    if (memo_first) {
+        sim_table_fill(S, sim_tbl, ST);
+        __syncthreads();
+    }
     // Step 1 (pica2.py:94-112)
     const uint32_t G = greedy_groups(S, idx, n_el, threshold, order, grp, gsz, rep, reinterpret_cast<uint32_t *>(rowsum));
-    // many groups: memoise the `match` identity by Hamming distance (same arithmetic, bit-identical values) — the
-    // G(G-1)/2 representative pairs then cost a table look-up each instead of a division and a decimal rounding;
-    // with few groups filling the table would cost more than it saves
-    __shared__ double sim_tbl[SIM_TBL_N];
-    if (G >= 48) {
+    if (!memo_first && G >= 48) {  // many groups: the G(G-1)/2 representative pairs then cost a look-up each
         sim_table_fill(S, sim_tbl, ST);
         __syncthreads();
     }
@@ -187,9 +193,44 @@ __global__ __launch_bounds__(ST) void pica2_kernel(SimBatch batch, const uint32_
 // directly.
 typedef int i32v4 __attribute__((ext_vector_type(4)));
 constexpr uint32_t HF_LDS_N = 4096;  // problems up to this many sequences keep class + Gram diagonal in LDS
+// Few, large problems (4096 haplotypes x a handful of windows): `splits` workgroups share a problem's member rows
+// (gridDim.y; rows k = 4 s + wave, step 4 splits) and leave partial sums in `part`; hfst_finish_kernel adds them up in
+// split order and does the arithmetic below.  splits == 1: everything in this kernel, as for the usual many-windows case.
+struct HfstPart {
+    double a, b, x;
+    uint64_t ca, cb, cx;
+};
+__device__ inline void hfst_outputs(double accA, double accB, double accX, uint64_t cA, uint64_t mA, uint64_t cB, uint64_t mB,
+                                    uint64_t cX, uint64_t mX, uint64_t L, HfstOut *__restrict__ dst) {
+    const double pi_a = cA ? accA / (double)cA : 0.0;  // h-fst.py:168-171
+    const double pi_b = cB ? accB / (double)cB : 0.0;
+    const double dxy = cX ? accX / (double)cX : 0.0;
+    const double pi_xy = 0.5 * (pi_a + pi_b);                   // :203
+    const double fst = (dxy > 0) ? (dxy - pi_xy) / dxy : 0.0;   // :214-221
+    HfstOut o;
+    if (L > 0) {  // :225-240
+        const double dl = (double)L;
+        o.v[0] = fst; o.v[1] = pi_a / dl; o.v[2] = pi_b / dl; o.v[3] = pi_xy / dl; o.v[4] = dxy / dl;
+        o.v[5] = (dxy - pi_xy) / dl;
+    } else {
+        o.v[0] = fst; o.v[1] = pi_a; o.v[2] = pi_b; o.v[3] = pi_xy; o.v[4] = dxy; o.v[5] = dxy - pi_xy;
+    }
+    o.cnt[0] = cA; o.cnt[1] = mA; o.cnt[2] = cB; o.cnt[3] = mB; o.cnt[4] = cX; o.cnt[5] = mX;
+    *dst = o;
+}
+__global__ void hfst_finish_kernel(const HfstPart *__restrict__ part, uint32_t splits, uint64_t n_problems,
+                                   const uint64_t *__restrict__ seq_len, HfstOut *__restrict__ out) {
+    const uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n_problems) return;
+    double a = 0.0, b = 0.0, x = 0.0;
+    for (uint32_t s = 0; s < splits; ++s) { a += part[p * splits + s].a; b += part[p * splits + s].b; x += part[p * splits + s].x; }
+    const HfstPart q = part[p * splits];
+    hfst_outputs(a, b, x, q.ca, 0, q.cb, 0, q.cx, 0, seq_len ? seq_len[p] : 0, out + p);
+}
+
 __global__ __launch_bounds__(ST) void hfst_kernel(SimBatch batch, const uint8_t *__restrict__ in_a,
                                                   const uint8_t *__restrict__ in_b, const uint64_t *__restrict__ seq_len,
-                                                  HfstOut *__restrict__ out) {
+                                                  HfstOut *__restrict__ out, HfstPart *__restrict__ part) {
     extern __shared__ __attribute__((aligned(16))) unsigned char hf_lds[];  // diag[n4] int32 | cls[n4] u8 | rows[n] u32 (n <= HF_LDS_N)
     __shared__ double shd[ST / 64];
     __shared__ uint64_t shu[ST / 64];
@@ -248,7 +289,7 @@ __global__ __launch_bounds__(ST) void hfst_kernel(SimBatch batch, const uint8_t 
         }
         __syncthreads();
         const uint32_t nm = n_members;
-        for (uint32_t k = tid >> 6; k < nm; k += ST / 64) {
+        for (uint32_t k = (tid >> 6) + (ST / 64) * blockIdx.y; k < nm; k += (ST / 64) * gridDim.y) {
             const uint32_t r = rows_l[k];
             const uint32_t cr = cls_l[r];
             const int64_t ar = S.diag[r];
@@ -298,22 +339,13 @@ __global__ __launch_bounds__(ST) void hfst_kernel(SimBatch batch, const uint8_t 
     cB = block_sum_u64(cB, shu); mB = block_sum_u64(mB, shu);
     cX = block_sum_u64(cX, shu); mX = block_sum_u64(mX, shu);
     if (tid == 0) {
-        const double pi_a = cA ? accA / (double)cA : 0.0;  // h-fst.py:168-171
-        const double pi_b = cB ? accB / (double)cB : 0.0;
-        const double dxy = cX ? accX / (double)cX : 0.0;
-        const double pi_xy = 0.5 * (pi_a + pi_b);                   // :203
-        const double fst = (dxy > 0) ? (dxy - pi_xy) / dxy : 0.0;   // :214-221
-        const uint64_t L = seq_len ? seq_len[prob] : 0;
-        HfstOut o;
-        if (L > 0) {  // :225-240
-            const double dl = (double)L;
-            o.v[0] = fst; o.v[1] = pi_a / dl; o.v[2] = pi_b / dl; o.v[3] = pi_xy / dl; o.v[4] = dxy / dl;
-            o.v[5] = (dxy - pi_xy) / dl;
+        if (gridDim.y > 1) {  // partial sums of this split; counts are the same in every split (analytic on Gram problems)
+            HfstPart q;
+            q.a = accA; q.b = accB; q.x = accX; q.ca = cA; q.cb = cB; q.cx = cX;
+            part[prob * gridDim.y + blockIdx.y] = q;
         } else {
-            o.v[0] = fst; o.v[1] = pi_a; o.v[2] = pi_b; o.v[3] = pi_xy; o.v[4] = dxy; o.v[5] = dxy - pi_xy;
+            hfst_outputs(accA, accB, accX, cA, mA, cB, mB, cX, mX, seq_len ? seq_len[prob] : 0, out + prob);
         }
-        o.cnt[0] = cA; o.cnt[1] = mA; o.cnt[2] = cB; o.cnt[3] = mB; o.cnt[4] = cX; o.cnt[5] = mX;
-        out[prob] = o;
     }
 }
 
@@ -521,9 +553,34 @@ int launch_hfst(impop_ctx *ctx, const SimBatch &b, uint64_t n_problems, const ui
     // diag[n4] int32 | cls[n4] u8 | (16-aligned) member rows[n] u32, n4 = n rounded up to 4
     const size_t n4 = ((size_t)b.n + 3) & ~(size_t)3;
     const size_t lds = b.n <= HF_LDS_N ? ((n4 * 5 + 15) & ~(size_t)15) + (size_t)b.n * 4 + 16 : 16;
-    hipLaunchKernelGGL(hfst_kernel, dim3((uint32_t)n_problems), dim3(ST), lds, ctx->stream, b, d_in_a, d_in_b, d_seq_len,
-                       d_out);
+    // one workgroup per problem fills the chip when there are thousands of problems; a few LARGE Gram problems are split
+    // over several workgroups each (about 8 per CU in total, never more than one per 16 rows)
+    uint32_t splits = 1;
+    if (b.gram && b.n >= 1024 && b.n <= HF_LDS_N && (b.ld & 3u) == 0) {
+        const uint64_t want = 8ull * (uint64_t)(ctx->n_cu > 0 ? ctx->n_cu : 256);
+        splits = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(want / n_problems, 1), b.n / 16);
+        if (splits > 1024) splits = 1024;
+    }
+    HfstPart *d_part = nullptr;
+    if (splits > 1) {
+        const size_t need = (size_t)n_problems * splits * sizeof(HfstPart);
+        if (need > ctx->part_bytes) {
+            HIP_TRY(hipStreamSynchronize(ctx->stream));
+            if (ctx->d_part) HIP_TRY(hipFree(ctx->d_part));
+            ctx->d_part = nullptr; ctx->part_bytes = 0;
+            HIP_TRY(hipMalloc(&ctx->d_part, need));
+            ctx->part_bytes = need;
+        }
+        d_part = reinterpret_cast<HfstPart *>(ctx->d_part);
+    }
+    hipLaunchKernelGGL(hfst_kernel, dim3((uint32_t)n_problems, splits), dim3(ST), lds, ctx->stream, b, d_in_a, d_in_b, d_seq_len,
+                       d_out, d_part);
     HIP_TRY(hipGetLastError());
+    if (splits > 1) {
+        hipLaunchKernelGGL(hfst_finish_kernel, dim3((uint32_t)((n_problems + 63) / 64)), dim3(64), 0, ctx->stream, d_part, splits,
+                           n_problems, d_seq_len, d_out);
+        HIP_TRY(hipGetLastError());
+    }
     return IMPOP_OK;
 }
 

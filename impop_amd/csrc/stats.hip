@@ -43,9 +43,28 @@ __device__ inline uint64_t block_sum_u64(uint64_t v, uint64_t *sh) {
 // by their smallest member; rep[g] (nullable) = that member's position, gsz[g] = group size.
 // scratch: 2*m u32 of LDS the caller can spare during grouping (only touched when order != nullptr).
 // All threads of the workgroup call this; returns the number of groups.
+// `match` identity of a Gram problem: round((W - H) / W) is non-increasing in the Hamming distance H, so "identity >
+// threshold" is "H <= H*" for one H* per problem (-1: never), found by bisection with the very function the pairs
+// would be tested with — the same decisions, three integer operations per pair instead of a division and a decimal
+// rounding.  Every thread computes the same value (about 32 evaluations).
+__device__ inline int64_t match_cutoff(const SimView &S, double thr) {
+    const int64_t W = (int64_t)S.W;
+    auto above = [&](int64_t H) { const double v = match_identity(S.W, H, S.round_digits); return v == v && v > thr; };
+    if (!above(0)) return -1;
+    int64_t lo = 0, hi = W > 0 ? W : 0;  // above(lo) holds
+    if (above(hi)) return hi;
+    while (hi - lo > 1) {
+        const int64_t mid = lo + (hi - lo) / 2;
+        if (above(mid)) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
 __device__ inline uint32_t greedy_groups(const SimView &S, const uint32_t *__restrict__ idx, uint32_t m, double thr,
                                          const uint32_t *__restrict__ order, uint32_t *grp, uint32_t *gsz, uint32_t *rep,
                                          uint32_t *scratch) {
+    const bool by_cutoff = S.gram && S.kind == IMPOP_IDENTITY_MATCH;
+    const int64_t hstar = by_cutoff ? match_cutoff(S, thr) : 0;
     __shared__ uint32_t chunk_cnt[ST];
     const uint32_t tid = threadIdx.x;
     for (uint32_t i = tid; i < m; i += ST) { grp[i] = NONE; gsz[i] = 0; }
@@ -59,8 +78,16 @@ __device__ inline uint32_t greedy_groups(const SimView &S, const uint32_t *__res
         // without an order everything below the seed is already grouped
         for (uint32_t o = (order ? 0 : seed + 1) + tid; o < m; o += ST) {
             if (o == seed || grp[o] != NONE) continue;
-            const double v = sim_get(S, es, idx ? idx[o] : o);
-            if (v == v && v > thr) { grp[o] = G; ++cnt; }  // strict > (pica2.py:106, hud.py:80)
+            const uint32_t eo = idx ? idx[o] : o;
+            bool joins;
+            if (by_cutoff) {
+                const int64_t ai = S.diag ? S.diag[es] : gram_at(S, es, es), aj = S.diag ? S.diag[eo] : gram_at(S, eo, eo);
+                joins = ai + aj - 2 * gram_at(S, es < eo ? es : eo, es < eo ? eo : es) <= hstar;
+            } else {
+                const double v = sim_get(S, es, eo);
+                joins = v == v && v > thr;  // strict > (pica2.py:106, hud.py:80)
+            }
+            if (joins) { grp[o] = G; ++cnt; }
         }
         __syncthreads();  // every thread has tested grp[seed] and its own candidates before the seed is marked
         if (tid == 0) { grp[seed] = G; ++cnt; if (rep) rep[G] = seed; }

@@ -14,7 +14,21 @@ typedef unsigned __int128 u128;
 // here in exact integer arithmetic: x = m * 2^sh, q = rint_even(m * 10^nd * 2^sh),
 // result = q / 10^nd (one correctly rounded IEEE division of two exact doubles ==
 // the double nearest to the decimal).  Valid for 0 <= nd <= 19.
+//
+// Fast path (what almost every call takes): t = x * 10^nd in fp64 is off the exact product by less than 2^-23 while
+// |t| < 2^30, so unless t sits within 1e-6 of a rounding boundary k + 1/2 the nearest integer of the exact product is
+// rint(t), and q / 10^nd is the same correctly rounded division the exact path ends with.  Boundary cases (and huge /
+// tiny arguments) fall through to the exact integer arithmetic below.
 __host__ __device__ inline double py_round(double x, int nd) {
+    if (nd >= 0 && nd <= 15) {
+        double p = 1.0;
+        for (int i = 0; i < nd; ++i) p *= 10.0;  // exact: 10^15 < 2^53
+        const double t = x * p;
+        if (t > -1073741824.0 && t < 1073741824.0) {  // also false for NaN
+            const double f = t - floor(t);
+            if (f < 0.5 - 1e-6 || f > 0.5 + 1e-6) return rint(t) / p;
+        }
+    }
     union { double d; uint64_t u; } cv;
     cv.d = x;
     const uint64_t bits = cv.u;

@@ -27,7 +27,7 @@ __global__ __launch_bounds__(256, 6) void scan(const uint32_t *__restrict__ sb, 
     const uint32_t lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     uint32_t s_all = 0, qa = 0, qb = 0, qab = 0;
     const uint64_t b0 = (uint64_t)blockIdx.x * TILE, b1 = b0 + TILE < n_block ? b0 + TILE : n_block;
-    for (uint64_t b = b0 + wave; b < b1; b += 4) {
+    auto one_block = [&](uint64_t b) {
         const uint32_t *blk = sb + b * BLK;
         uint32_t w[15];
         u32x4 v0 = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(blk + lane * 4));
@@ -57,10 +57,12 @@ __global__ __launch_bounds__(256, 6) void scan(const uint32_t *__restrict__ sb, 
         }
         s_all += (c - 1u) < 464u;
         qa += __umul24(cA, nA - cA); qb += __umul24(cB, nB - cB); qab += __umul24(cA, nB - cB) + __umul24(cB, nA - cA);
-    }
-    const uint32_t t = s_all ^ qa ^ qb ^ qab;
+    };
+    uint64_t b = b0 + wave;
+    for (; b + 4 < b1; b += 8) { one_block(b); one_block(b + 4); }
+    for (; b < b1; b += 4) one_block(b);
+    const uint32_t t = s_all ^ qa ^ qb ^ qab;  // depends on every loaded word: the loads cannot be dropped
     if (t == 0x12345678u) out[0] = t;
-    atomicAdd(out + 1, (unsigned long long)s_all);  // keep the work alive
 }
 
 template <int LAYOUT>

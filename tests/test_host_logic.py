@@ -123,3 +123,35 @@ def test_fst_3pi_known_answer():
     assert pica_cell(2.093e-05, 1000) == "0.00002093 (sequence length: 1000)"
     rec = {"n_sites": 100, "sum_a": 30, "sum_b": 12, "sum_ab": 58}
     assert pi_union_site(rec, 3, 2, 100) == 100 / (10.0 * 100) / 100
+
+
+def test_c_abi_shard_rule_equals_python_rule():
+    """impop_shard_range / impop_shard_windows are host arithmetic (no GPU): the C rule behind impop_scan_sharded and
+    impop_gather_records is the rule of impop_amd.distributed (first n % shards ranges one window longer; the slab of a
+    shard is the union of its windows' sites, halo included)."""
+    import ctypes as C
+
+    import impop_amd
+    from impop_amd import _lib
+    from impop_amd.distributed import shard_range, shard_windows
+    lib = _lib.load()
+    for n in (0, 1, 7, 64, 1000, 4854):
+        for world in (1, 2, 3, 8, 13):
+            covered = 0
+            for r in range(world):
+                f, c = C.c_uint64(), C.c_uint64()
+                assert lib.impop_shard_range(n, world, r, C.byref(f), C.byref(c)) == 0
+                lo, hi = shard_range(n, world, r)
+                assert (f.value, f.value + c.value) == (lo, hi)
+                covered += c.value
+            assert covered == n
+    f, c = C.c_uint64(), C.c_uint64()
+    assert lib.impop_shard_range(10, 0, 0, C.byref(f), C.byref(c)) == _lib.E_INVALID
+    assert lib.impop_shard_range(10, 4, 4, C.byref(f), C.byref(c)) == _lib.E_INVALID
+    for size, step in ((1000, None), (1000, 500), (700, 300)):
+        wins = impop_amd.fixed_windows(12345, size, step)
+        for world in (1, 2, 5):
+            for r in range(world):
+                got = impop_amd.shard_windows_c(wins, world, r)
+                loc, s0, s1, (lo, hi) = shard_windows(wins, world, r)
+                assert got == (lo, hi - lo, s0, s1), (size, step, world, r, got)

@@ -39,6 +39,19 @@ int ctx_scratch(impop_ctx *ctx, size_t bytes, void **out) {
     return IMPOP_OK;
 }
 
+int ctx_aux(impop_ctx *ctx, int slot, size_t bytes, void **out) {
+    if (bytes > ctx->aux_bytes[slot]) {
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        if (ctx->d_aux[slot]) HIP_TRY(hipFree(ctx->d_aux[slot]));
+        ctx->d_aux[slot] = nullptr;
+        ctx->aux_bytes[slot] = 0;
+        HIP_TRY(hipMalloc(&ctx->d_aux[slot], bytes + (bytes >> 2)));
+        ctx->aux_bytes[slot] = bytes + (bytes >> 2);
+    }
+    *out = ctx->d_aux[slot];
+    return IMPOP_OK;
+}
+
 __global__ void tajima_consts_kernel(int64_t n, double *out) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
         TajConsts c = tajima_consts(n);
@@ -122,7 +135,8 @@ IMPOP_API int impop_ctx_destroy(impop_ctx *ctx) {
     if (ctx->d_taj) hipFree(ctx->d_taj);
     if (ctx->d_queue) hipFree(ctx->d_queue);
     if (ctx->scratch) hipFree(ctx->scratch);
-    if (ctx->d_part) hipFree(ctx->d_part);
+    for (void *a : ctx->d_aux)
+        if (a) hipFree(a);
     if (ctx->side) { hipStreamSynchronize(ctx->side); hipStreamDestroy(ctx->side); }
     if (ctx->ev_fork) hipEventDestroy(ctx->ev_fork);
     if (ctx->ev_join) hipEventDestroy(ctx->ev_join);

@@ -95,8 +95,10 @@ struct impop_ctx {
     // growable scratch
     void *scratch = nullptr;
     size_t scratch_bytes = 0;
-    void *d_part = nullptr;  // partial sums of split epilogue problems (stats.hip launch_hfst)
-    size_t part_bytes = 0;
+    // growable side buffers of the epilogue kernels that split large problems over several workgroups (stats.hip):
+    // slot 0 h-fst partial sums, slot 1 pica2 group tables + row sums; separate because the two run side by side
+    void *d_aux[2] = {nullptr, nullptr};
+    size_t aux_bytes[2] = {0, 0};
 };
 
 struct impop_matrix {
@@ -137,6 +139,7 @@ struct impop_matrix {
 
 namespace impop {
 int ctx_scratch(impop_ctx *ctx, size_t bytes, void **out);
+int ctx_aux(impop_ctx *ctx, int slot, size_t bytes, void **out);
 int ensure_tajima_consts(impop_ctx *ctx, int64_t n);  // fills ctx->d_taj for n (device kernel)
 
 // windows are given in ORIGINAL site coordinates; for a compacted matrix map them to kept-site index

@@ -75,19 +75,34 @@ __device__ inline uint32_t greedy_groups(const SimView &S, const uint32_t *__res
         if (grp[seed] != NONE) continue;  // uniform across the workgroup
         const uint32_t es = idx ? idx[seed] : seed;
         uint32_t cnt = 0;
-        // without an order everything below the seed is already grouped
-        for (uint32_t o = (order ? 0 : seed + 1) + tid; o < m; o += ST) {
-            if (o == seed || grp[o] != NONE) continue;
-            const uint32_t eo = idx ? idx[o] : o;
-            bool joins;
-            if (by_cutoff) {
-                const int64_t ai = S.diag ? S.diag[es] : gram_at(S, es, es), aj = S.diag ? S.diag[eo] : gram_at(S, eo, eo);
-                joins = ai + aj - 2 * gram_at(S, es < eo ? es : eo, es < eo ? eo : es) <= hstar;
-            } else {
-                const double v = sim_get(S, es, eo);
-                joins = v == v && v > thr;  // strict > (pica2.py:106, hud.py:80)
+        // without an order everything below the seed is already grouped.  Candidates in batches of GG_U per thread: all
+        // Gram / table loads of a batch go out before the first is consumed (one at a time, a step of this serial loop
+        // cost a full memory latency per candidate: 15 us per group at 4096 elements)
+        constexpr int GG_U = 8;
+        const int64_t a_seed = by_cutoff ? (S.diag ? (int64_t)S.diag[es] : gram_at(S, es, es)) : 0;
+        for (uint32_t o0 = (order ? 0 : seed + 1) + tid; o0 < m; o0 += ST * GG_U) {
+            int64_t hv[GG_U];
+            double sv[GG_U];
+#pragma unroll
+            for (int u = 0; u < GG_U; ++u) {
+                const uint32_t o = o0 + u * ST;
+                hv[u] = 0; sv[u] = 0.0;
+                if (o >= m || o == seed) continue;
+                const uint32_t eo = idx ? idx[o] : o;
+                if (by_cutoff) {
+                    const int64_t aj = S.diag ? (int64_t)S.diag[eo] : gram_at(S, eo, eo);
+                    hv[u] = a_seed + aj - 2 * gram_at(S, es < eo ? es : eo, es < eo ? eo : es);
+                } else {
+                    sv[u] = sim_get(S, es, eo);
+                }
             }
-            if (joins) { grp[o] = G; ++cnt; }
+#pragma unroll
+            for (int u = 0; u < GG_U; ++u) {
+                const uint32_t o = o0 + u * ST;
+                if (o >= m || o == seed || grp[o] != NONE) continue;
+                const bool joins = by_cutoff ? hv[u] <= hstar : (sv[u] == sv[u] && sv[u] > thr);  // strict > (pica2.py:106, hud.py:80)
+                if (joins) { grp[o] = G; ++cnt; }
+            }
         }
         __syncthreads();  // every thread has tested grp[seed] and its own candidates before the seed is marked
         if (tid == 0) { grp[seed] = G; ++cnt; if (rep) rep[G] = seed; }
@@ -127,10 +142,21 @@ __device__ inline uint32_t greedy_groups(const SimView &S, const uint32_t *__res
 // pica2.analyze_similarity_matrix (pica2.py:60-169).  Elements are idx[0..n_el) (or 0..n_el
 // when idx == nullptr), already in lexicographic name order; `order`: see greedy_groups.
 // dynamic LDS: rowsum[n_el] f64 (grouping scratch before step 2) | grp[n_el] u32 | rep[n_el] u32 | gsz[n_el] u32
+// Large problems (>= 1024 elements, few of them): the G(G-1)/2 representative pairs of Step 2 are more work than one
+// workgroup should do alone (4096 singleton groups: 8.4 M identities, 45 ms on four waves).  pica2_kernel then stops
+// after the grouping and leaves rep / group size / G in `split` (per problem: 2 n_el + 4 dwords, then n_el doubles of
+// row sums); pica2_rows_kernel (grid: problems x row chunks) fills the row sums; pica2_finish_kernel adds them in row
+// order and writes the record.  Small problems do everything in pica2_kernel, as before.
+struct Pica2Split {
+    uint32_t *tab;     // problem p: rep[n_el] | gsz[n_el] | G | have | npairs lo | npairs hi
+    double *rowsum;    // problem p: n_el doubles
+};
+__device__ inline uint32_t *split_tab(const Pica2Split &sp, uint64_t p, uint32_t n_el) { return sp.tab + p * (2ull * n_el + 4); }
+
 __global__ __launch_bounds__(ST) void pica2_kernel(SimBatch batch, const uint32_t *__restrict__ idx, uint32_t n_el,
                                                    const uint32_t *__restrict__ order, double threshold,
                                                    const uint64_t *__restrict__ seq_len, Pica2Out *__restrict__ out,
-                                                   uint32_t *__restrict__ group_of) {
+                                                   uint32_t *__restrict__ group_of, Pica2Split split) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     double *rowsum = reinterpret_cast<double *>(lds_raw);
     uint32_t *grp = reinterpret_cast<uint32_t *>(rowsum + n_el);
@@ -164,24 +190,66 @@ __global__ __launch_bounds__(ST) void pica2_kernel(SimBatch batch, const uint32_
         sim_table_fill(S, sim_tbl, ST);
         __syncthreads();
     }
+    if (split.tab) {  // large problem: hand the groups over, Step 2 runs in pica2_rows_kernel
+        uint32_t *tab = split_tab(split, prob, n_el);
+        for (uint32_t g = tid; g < G; g += ST) { tab[g] = rep[g]; tab[n_el + g] = gsz[g]; }
+        if (tid == 0) { tab[2 * n_el] = G; tab[2 * n_el + 1] = 0; tab[2 * n_el + 2] = 0; tab[2 * n_el + 3] = 0; }
+        if (group_of)
+            for (uint32_t i = tid; i < n_el; i += ST) group_of[prob * n_el + i] = grp[i];
+        return;
+    }
     // Step 2-3 (pica2.py:118-154): sum over group pairs of 2*(1-sim(rep_i,rep_j))*f_i*f_j
     const double total = (double)n_el;
     uint32_t have = 0;
     uint64_t npairs = 0;
-    for (uint32_t i = tid; i < G; i += ST) {
-        const uint32_t ri = idx ? idx[rep[i]] : rep[i];
-        const double fi = (double)gsz[i] / total;
-        double acc = 0.0;
-        for (uint32_t j = i + 1; j < G; ++j) {
-            const double s = sim_get(S, ri, idx ? idx[rep[j]] : rep[j]);
-            if (s != s) continue;  // missing pair skipped (pica2.py:132-134)
-            const double fj = (double)gsz[j] / total;
-            const double pv = (1 - s) * fi * fj;
-            acc += 2 * pv;
-            have = 1;
-            ++npairs;
+    if (G <= 64) {
+        // few groups (the usual case): a thread per row, the row's pairs in the reference's order
+        for (uint32_t i = tid; i < G; i += ST) {
+            const uint32_t ri = idx ? idx[rep[i]] : rep[i];
+            const double fi = (double)gsz[i] / total;
+            double acc = 0.0;
+            for (uint32_t j = i + 1; j < G; ++j) {
+                const double s = sim_get(S, ri, idx ? idx[rep[j]] : rep[j]);
+                if (s != s) continue;  // missing pair skipped (pica2.py:132-134)
+                const double fj = (double)gsz[j] / total;
+                const double pv = (1 - s) * fi * fj;
+                acc += 2 * pv;
+                have = 1;
+                ++npairs;
+            }
+            rowsum[i] = acc;
         }
-        rowsum[i] = acc;
+    } else {
+        // many groups: a WAVE per row, lanes along the row — the representatives' Gram / table row is read coalesced
+        // (a thread per row read one cache line per lane and pair: 4096 singleton groups cost 94 ms per window) —
+        // lane partials in j order, fixed butterfly across lanes
+        const uint32_t lane = tid & 63;
+        for (uint32_t i = tid >> 6; i < G; i += ST / 64) {
+            const uint32_t ri = idx ? idx[rep[i]] : rep[i];
+            const double fi = (double)gsz[i] / total;
+            double acc = 0.0;
+            constexpr int P2_U = 8;  // identities in flight per lane: one at a time this loop is a chain of memory latencies
+            for (uint32_t j0 = i + 1 + lane; j0 < G; j0 += 64 * P2_U) {
+                double sv[P2_U];
+#pragma unroll
+                for (int u = 0; u < P2_U; ++u) {
+                    const uint32_t j = j0 + 64 * u;
+                    sv[u] = j < G ? sim_get(S, ri, idx ? idx[rep[j]] : rep[j]) : __builtin_nan("");
+                }
+#pragma unroll
+                for (int u = 0; u < P2_U; ++u) {
+                    const uint32_t j = j0 + 64 * u;
+                    const double s = sv[u];
+                    if (j >= G || s != s) continue;
+                    const double fj = (double)gsz[j] / total;
+                    acc += 2 * ((1 - s) * fi * fj);
+                    have = 1;
+                    ++npairs;
+                }
+            }
+            acc = wave_sum_f64(acc);
+            if (lane == 0) rowsum[i] = acc;
+        }
     }
     if (have) atomicOr(&sh_have, 1u);
     if (npairs) atomicAdd((unsigned long long *)&sh_npairs, (unsigned long long)npairs);
@@ -202,6 +270,86 @@ __global__ __launch_bounds__(ST) void pica2_kernel(SimBatch batch, const uint32_
     }
     if (group_of)
         for (uint32_t i = tid; i < n_el; i += ST) group_of[prob * n_el + i] = grp[i];
+}
+
+// Step 2 of a large problem: workgroup (p, c) takes the group rows i = 4 c + wave, step 4 gridDim.y — a wave per row,
+// lanes along the row, eight identities in flight per lane — and writes row sums; pair counts by integer atomics.
+// dynamic LDS: diag[batch.n] int32 (Gram problems)
+__global__ __launch_bounds__(ST) void pica2_rows_kernel(SimBatch batch, const uint32_t *__restrict__ idx, uint32_t n_el,
+                                                        Pica2Split split) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    __shared__ double sim_tbl[SIM_TBL_N];
+    const uint64_t prob = blockIdx.x;
+    SimView S = sim_view(batch, prob);
+    const uint32_t tid = threadIdx.x, lane = tid & 63;
+    if (S.gram) {
+        int32_t *diag_l = reinterpret_cast<int32_t *>(lds_raw);
+        for (uint32_t i = tid; i < batch.n; i += ST) diag_l[i] = (int32_t)gram_at(S, i, i);
+        S.diag = diag_l;
+    }
+    sim_table_fill(S, sim_tbl, ST);
+    __syncthreads();
+    uint32_t *tab = split_tab(split, prob, n_el);
+    const uint32_t *rep = tab, *gsz = tab + n_el;
+    const uint32_t G = tab[2 * n_el];
+    double *rowsum = split.rowsum + prob * n_el;
+    const double total = (double)n_el;
+    uint32_t have = 0;
+    uint64_t npairs = 0;
+    constexpr int P2_U = 8;
+    for (uint32_t i = (tid >> 6) + (ST / 64) * blockIdx.y; i < G; i += (ST / 64) * gridDim.y) {
+        const uint32_t ri = idx ? idx[rep[i]] : rep[i];
+        const double fi = (double)gsz[i] / total;
+        double acc = 0.0;
+        for (uint32_t j0 = i + 1 + lane; j0 < G; j0 += 64 * P2_U) {
+            double sv[P2_U];
+#pragma unroll
+            for (int u = 0; u < P2_U; ++u) {
+                const uint32_t j = j0 + 64 * u;
+                sv[u] = j < G ? sim_get(S, ri, idx ? idx[rep[j]] : rep[j]) : __builtin_nan("");
+            }
+#pragma unroll
+            for (int u = 0; u < P2_U; ++u) {
+                const uint32_t j = j0 + 64 * u;
+                const double s = sv[u];
+                if (j >= G || s != s) continue;  // missing pair skipped (pica2.py:132-134)
+                const double fj = (double)gsz[j] / total;
+                acc += 2 * ((1 - s) * fi * fj);
+                have = 1;
+                ++npairs;
+            }
+        }
+        acc = wave_sum_f64(acc);
+        if (lane == 0) rowsum[i] = acc;
+    }
+    npairs = wave_sum_u64(npairs);
+    if (lane == 0 && npairs) {
+        atomicOr(&tab[2 * n_el + 1], 1u);
+        atomicAdd(reinterpret_cast<unsigned long long *>(tab + 2 * n_el + 2), (unsigned long long)npairs);
+    }
+    (void)have;
+}
+
+__global__ void pica2_finish_kernel(Pica2Split split, uint32_t n_el, uint64_t n_problems, const uint64_t *__restrict__ seq_len,
+                                    Pica2Out *__restrict__ out) {
+    const uint64_t prob = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (prob >= n_problems) return;
+    const uint32_t *tab = split_tab(split, prob, n_el);
+    const uint32_t G = tab[2 * n_el];
+    const double *rowsum = split.rowsum + prob * n_el;
+    double acc = 0.0;
+    for (uint32_t i = 0; i + 1 < G; ++i) acc += rowsum[i];  // the last row has no pair to its right
+    double pi = 0.0, pi_site = 0.0;
+    if (n_el != 0 && tab[2 * n_el + 1]) {
+        pi = ((double)n_el / (double)(n_el - 1)) * acc;  // pica2.py:154
+        const uint64_t L = seq_len ? seq_len[prob] : 0;
+        pi_site = L ? pi / (double)L : __builtin_nan("");
+    }
+    Pica2Out o;
+    o.pi = pi; o.pi_site = pi_site; o.n_groups = G; o.pad = 0;
+    o.sum_2pairs = acc;
+    o.n_pairs = (uint64_t)tab[2 * n_el + 2] | ((uint64_t)tab[2 * n_el + 3] << 32);
+    out[prob] = o;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -565,11 +713,35 @@ int launch_pica2(impop_ctx *ctx, const SimBatch &b, uint64_t n_problems, const u
     const size_t lds = (size_t)n_el * (8 + 12) + (b.gram ? (size_t)b.n * 4 : 0) + 16;
     REQUIRE(lds <= 150 * 1024, "pica2: %u elements exceed the LDS-resident grouping limit (7600; 6300 on Gram problems)", n_el);
     REQUIRE(n_problems < 0x7FFFFFFFull, "pica2: too many problems");
+    // few large problems: Step 2 is split over row chunks (about 8 workgroups per CU in total, >= 16 rows each)
+    uint32_t chunks = 1;
+    if (n_el >= 1024) {
+        const uint64_t want = 8ull * (uint64_t)(ctx->n_cu > 0 ? ctx->n_cu : 256);
+        chunks = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(want / n_problems, 1), n_el / 16);
+        if (chunks > 1024) chunks = 1024;
+    }
+    Pica2Split split{nullptr, nullptr};
+    if (chunks > 1) {
+        const size_t tab_bytes = ((size_t)n_problems * (2ull * n_el + 4) * 4 + 255) / 256 * 256;
+        void *aux = nullptr;
+        const int arc = ctx_aux(ctx, 1, tab_bytes + (size_t)n_problems * n_el * 8, &aux);
+        if (arc) return arc;
+        split.tab = reinterpret_cast<uint32_t *>(aux);
+        split.rowsum = reinterpret_cast<double *>((char *)aux + tab_bytes);
+    }
     if (lds > 48 * 1024)
         HIP_TRY(hipFuncSetAttribute((const void *)pica2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(pica2_kernel, dim3((uint32_t)n_problems), dim3(ST), lds, ctx->stream, b, d_idx, n_el, d_order,
-                       threshold, d_seq_len, d_out, d_group_of);
+                       threshold, d_seq_len, d_out, d_group_of, split);
     HIP_TRY(hipGetLastError());
+    if (chunks > 1) {
+        hipLaunchKernelGGL(pica2_rows_kernel, dim3((uint32_t)n_problems, chunks), dim3(ST), b.gram ? (size_t)b.n * 4 : 0, ctx->stream, b,
+                           d_idx, n_el, split);
+        HIP_TRY(hipGetLastError());
+        hipLaunchKernelGGL(pica2_finish_kernel, dim3((uint32_t)((n_problems + 63) / 64)), dim3(64), 0, ctx->stream, split, n_el,
+                           n_problems, d_seq_len, d_out);
+        HIP_TRY(hipGetLastError());
+    }
     return IMPOP_OK;
 }
 
@@ -590,15 +762,10 @@ int launch_hfst(impop_ctx *ctx, const SimBatch &b, uint64_t n_problems, const ui
     }
     HfstPart *d_part = nullptr;
     if (splits > 1) {
-        const size_t need = (size_t)n_problems * splits * sizeof(HfstPart);
-        if (need > ctx->part_bytes) {
-            HIP_TRY(hipStreamSynchronize(ctx->stream));
-            if (ctx->d_part) HIP_TRY(hipFree(ctx->d_part));
-            ctx->d_part = nullptr; ctx->part_bytes = 0;
-            HIP_TRY(hipMalloc(&ctx->d_part, need));
-            ctx->part_bytes = need;
-        }
-        d_part = reinterpret_cast<HfstPart *>(ctx->d_part);
+        void *aux = nullptr;
+        const int arc = ctx_aux(ctx, 0, (size_t)n_problems * splits * sizeof(HfstPart), &aux);
+        if (arc) return arc;
+        d_part = reinterpret_cast<HfstPart *>(aux);
     }
     hipLaunchKernelGGL(hfst_kernel, dim3((uint32_t)n_problems, splits), dim3(ST), lds, ctx->stream, b, d_in_a, d_in_b, d_seq_len,
                        d_out, d_part);

@@ -1202,3 +1202,46 @@ def test_all_pairs_path_on_compacted_matrix(ctx, oracle):
     with pytest.raises(impop_amd.ImpopError):
         c2.pairwise_counts(0, 10)
     c2.free(); src.free()
+
+
+def test_large_problems_split_epilogues(ctx, oracle):
+    """>= 1024 elements: pica2's Step 2 runs as row chunks over many workgroups (pica2_rows_kernel + finish) and h-fst's
+    member rows are split likewise; both must agree with the oracle — on a Gram problem straight from the bit matrix
+    (few groups and all-singleton groups), on a dense `.sim`-style table with missing pairs, and with a seed order."""
+    rng = np.random.default_rng(41)
+    n, W = 1100, 3000
+    f = (rng.random((7, W)) < 0.5).astype(np.uint8)
+    who = rng.integers(0, 7, size=n)
+    m = f[who] ^ (rng.random((n, W)) < 0.0006).astype(np.uint8)
+    bm = ctx.upload_dense(m, keep_hap_major=True)
+    bits = oracle.pack_hap_major(m)
+    inA = (rng.random(n) < 0.45).astype(np.uint8); inB = (rng.random(n) < 0.45).astype(np.uint8)
+    wins = [(0, W, W), (100, 2100, 5000)]
+    for kind, kid in (("match", 0), ("dice", 1)):
+        for thr, rd in ((0.999, 5), (0.9995, None), (1.0, None)):   # a few dozen groups ... every haplotype its own group
+            got = bm.pairwise_scan(wins, None, inA, inB, kind=kind, threshold=thr, round_digits=rd, s_scope=2)
+            for (s0, s1, L), r in zip(wins, got):
+                sim = oracle.identity(oracle.pairwise_counts(bits, n, s0, s1), s1 - s0, kid)
+                pi, ps, _, G = oracle.pica2(sim, thr, L, rd)
+                assert int(r["n_groups"]) == G, (kind, thr, rd, int(r["n_groups"]), G)
+                assert rel_close(float(r["pi"]), pi, REL, 1e-300) and rel_close(float(r["pi_site"]), ps, REL, 1e-300), (kind, thr, rd)
+                h, _ = oracle.hfst(sim, inA, inB, L, rd)
+                for k in ("fst", "pi_a", "pi_b", "pi_xy", "dxy", "da"):
+                    assert rel_close(float(r[k]), h[k], REL, 1e-300), (kind, thr, rd, k)
+    # dense table with missing pairs and a seed order (the .sim drop-in path at n >= 1024)
+    sim = oracle.identity(oracle.pairwise_counts(bits, n, 0, W), W, 0)
+    drop = rng.random((n, n)) < 0.01
+    sim[np.triu(drop, 1) | np.triu(drop, 1).T] = np.nan
+    rank = rng.permutation(n).astype(np.uint32)
+    for thr, rd in ((0.9992, 4), (0.99, None)):
+        pi, ps, grp, G, (sum2, npairs) = ctx.pi_from_identity(sim, thr, rd, 777, seed_rank=rank, detail=True)
+        opi, ops, ogrp, oG = oracle.pica2(sim, thr, 777, rd, seed_rank=rank)
+        assert G == oG and (grp == ogrp).all()
+        assert rel_close(pi, opi, REL, 1e-300) and rel_close(ps, ops, REL, 1e-300)
+        assert rel_close(pi, n / (n - 1) * sum2, 1e-14) and npairs <= G * (G - 1) // 2
+        out, cnt = ctx.fst_from_identity(sim, inA, inB, 777, rd)
+        want, wcnt = oracle.hfst(sim, inA, inB, 777, rd)
+        for k, key in enumerate(("fst", "pi_a", "pi_b", "pi_xy", "dxy", "da")):
+            assert rel_close(float(out[k]), want[key], REL, 1e-300), key
+        assert (cnt == wcnt).all()
+    bm.free()

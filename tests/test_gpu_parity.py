@@ -1227,7 +1227,8 @@ def test_large_problems_split_epilogues(ctx, oracle):
                 assert rel_close(float(r["pi"]), pi, REL, 1e-300) and rel_close(float(r["pi_site"]), ps, REL, 1e-300), (kind, thr, rd)
                 h, _ = oracle.hfst(sim, inA, inB, L, rd)
                 for k in ("fst", "pi_a", "pi_b", "pi_xy", "dxy", "da"):
-                    assert rel_close(float(r[k]), h[k], REL, 1e-300), (kind, thr, rd, k)
+                    # random populations: Fst / Da are differences of nearly equal means, so an absolute floor for them
+                    assert rel_close(float(r[k]), h[k], REL, 1e-12 if k in ("fst", "da") else 1e-300), (kind, thr, rd, k)
     # dense table with missing pairs and a seed order (the .sim drop-in path at n >= 1024)
     sim = oracle.identity(oracle.pairwise_counts(bits, n, 0, W), W, 0)
     drop = rng.random((n, n)) < 0.01
@@ -1242,6 +1243,6 @@ def test_large_problems_split_epilogues(ctx, oracle):
         out, cnt = ctx.fst_from_identity(sim, inA, inB, 777, rd)
         want, wcnt = oracle.hfst(sim, inA, inB, 777, rd)
         for k, key in enumerate(("fst", "pi_a", "pi_b", "pi_xy", "dxy", "da")):
-            assert rel_close(float(out[k]), want[key], REL, 1e-300), key
+            assert rel_close(float(out[k]), want[key], REL, 1e-12 if key in ("fst", "da") else 1e-300), key
         assert (cnt == wcnt).all()
     bm.free()

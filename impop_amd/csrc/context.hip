@@ -147,6 +147,7 @@ IMPOP_API int impop_ctx_destroy(impop_ctx *ctx) {
 
 IMPOP_API int impop_ctx_synchronize(impop_ctx *ctx) {
     REQUIRE(ctx, "impop_ctx_synchronize: ctx is NULL");
+    HIP_TRY(hipSetDevice(ctx->device));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     return IMPOP_OK;
 }

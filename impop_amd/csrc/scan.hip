@@ -800,6 +800,8 @@ IMPOP_API int impop_scan_plan_launch(impop_scan_plan *p, void *d_out) {
     REQUIRE(p, "impop_scan_plan_launch: plan is NULL");
     impop_ctx *ctx = p->ctx;
     hipStream_t st = ctx->stream;
+    // one process may drive several devices (impop_scan_sharded): kernels go to the device the plan's stream lives on
+    HIP_TRY(hipSetDevice(ctx->device));
     // the cached Tajima constants belong to the context; another plan may have changed n since
     int rc = ensure_tajima_consts(ctx, p->ps.nP >= 2 ? (int64_t)p->ps.nP : 2);
     if (rc) return rc;
@@ -856,6 +858,7 @@ IMPOP_API int impop_scan_plan_launch(impop_scan_plan *p, void *d_out) {
 
 IMPOP_API int impop_scan_plan_fetch(impop_scan_plan *p, impop_window_stats *out_host) {
     REQUIRE(p && (out_host || p->n_windows == 0), "impop_scan_plan_fetch: NULL argument");
+    HIP_TRY(hipSetDevice(p->ctx->device));
     if (p->n_windows)
         HIP_TRY(hipMemcpyAsync(out_host, p->d_out, p->n_windows * sizeof(impop_window_stats), hipMemcpyDeviceToHost,
                                p->ctx->stream));
@@ -878,6 +881,7 @@ IMPOP_API int impop_scan_plan_info(const impop_scan_plan *p, uint64_t *n_tiles, 
 
 IMPOP_API int impop_scan_plan_timing(impop_scan_plan *p, int enable) {
     REQUIRE(p, "impop_scan_plan_timing: plan is NULL");
+    HIP_TRY(hipSetDevice(p->ctx->device));
     HIP_TRY(hipStreamSynchronize(p->ctx->stream));
     p->timing = enable != 0;
     p->events_used = 0;
@@ -886,6 +890,7 @@ IMPOP_API int impop_scan_plan_timing(impop_scan_plan *p, int enable) {
 
 IMPOP_API int impop_scan_plan_elapsed(impop_scan_plan *p, double *total_ms, uint64_t *launches) {
     REQUIRE(p, "impop_scan_plan_elapsed: plan is NULL");
+    HIP_TRY(hipSetDevice(p->ctx->device));
     HIP_TRY(hipStreamSynchronize(p->ctx->stream));
     double t = 0.0;
     for (size_t i = 0; i < p->events_used; ++i) {

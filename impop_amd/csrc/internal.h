@@ -140,6 +140,8 @@ struct impop_matrix {
 namespace impop {
 int ctx_scratch(impop_ctx *ctx, size_t bytes, void **out);
 int ctx_aux(impop_ctx *ctx, int slot, size_t bytes, void **out);
+// pairwise.hip: build (once) the bitmap of the sites that segregate among all haplotypes, m->d_segmap
+int ensure_segmap(impop_ctx *ctx, const impop_matrix *m);
 int ensure_tajima_consts(impop_ctx *ctx, int64_t n);  // fills ctx->d_taj for n (device kernel)
 
 // windows are given in ORIGINAL site coordinates; for a compacted matrix map them to kept-site index

@@ -237,6 +237,8 @@ IMPOP_API int impop_matrix_upload(impop_ctx *ctx, const uint64_t *bits, uint32_t
     if (want_rb) {
         rc = launch_sb_to_hm(ctx, m->d_sb, m->g, 0, m->g.n_block, m->d_rb, 0, m->n_hap_pad, m->rb_nb);
         if (rc) return fail(rc);
+        rc = ensure_segmap(ctx, m);  // a matrix kept for the all-pairs path gets its site bitmap (S per window) right away
+        if (rc) return fail(rc);
     }
     e = hipStreamSynchronize(ctx->stream);  // the caller may free `bits` on return
     if (e != hipSuccess) return fail(hip_fail(e, "hipStreamSynchronize", __FILE__, __LINE__));
@@ -290,6 +292,8 @@ IMPOP_API int impop_matrix_synthetic(impop_ctx *ctx, uint32_t n_hap, uint64_t n_
         if ((e = hipGetLastError()) != hipSuccess) return fail(hip_fail(e, "synth_sb_kernel", __FILE__, __LINE__));
         if (want_hm) {
             rc = launch_sb_to_hm(ctx, m->d_sb, m->g, 0, m->g.n_block, m->d_rb, 0, m->n_hap_pad, m->rb_nb);
+            if (rc) return fail(rc);
+            rc = ensure_segmap(ctx, m);
             if (rc) return fail(rc);
         }
     }

@@ -775,7 +775,7 @@ static inline void map_range(const impop_matrix *m, uint64_t s0, uint64_t s1, ui
     *k1 = (uint64_t)(std::lower_bound(m->pos.begin(), m->pos.end(), s1) - m->pos.begin());
 }
 
-static int ensure_segmap(impop_ctx *ctx, const impop_matrix *m) {
+int ensure_segmap(impop_ctx *ctx, const impop_matrix *m) {
     if (m->d_segmap || m->g.n_block == 0) return IMPOP_OK;
     HIP_TRY(hipMalloc((void **)&m->d_segmap, m->g.n_block * 8 + 256));
     REQUIRE((m->g.n_block + 3) / 4 < 0x7FFFFFFFull, "site bitmap: matrix too long for one launch");

@@ -419,14 +419,28 @@ __global__ __launch_bounds__(256) void site_counts_kernel(const uint32_t *__rest
 // Per tile: sum_k c_k (n_k - c_k) for every population and sum_s [c_k (n_l - c_l) + c_l (n_k - c_k)] for
 // every pair k < l.  Masks come from memory (wave-uniform scalar loads); K is a template parameter so
 // that the per-lane accumulators are registers.  out: tile-major, K + K(K-1)/2 uint64 per tile.
-template <int K>
+// Round 2: masks of all K populations in LDS (K x wps dwords, broadcast ds_read_b128), granules loaded four at a time
+// (the first version had ONE load in flight per wave), and for unweighted matrices of <= 512 haplotypes (SMALL) the
+// per-site work is K + K + K(K-1)/2 32-bit multiply-adds — sum c_k, sum c_k^2, sum c_k c_l — from which the tile's
+//   sum_s c_k (n_k - c_k) = n_k sum c_k - sum c_k^2,   sum_s [c_k (n_l - c_l) + c_l (n_k - c_k)] = n_l sum c_k + n_k sum c_l - 2 sum c_k c_l
+// follow once per lane and tile (every partial sum stays below 2^32: <= 1024 sites per lane and tile, products < 2^18);
+// the first version did three to four 64-bit multiplies per pair and site, which made K = 8 VALU-bound.
+template <int K, bool SMALL>
 __global__ __launch_bounds__(256) void scan_multi_kernel(const uint32_t *__restrict__ sb, const ScanTile *__restrict__ tiles,
                                                          const uint32_t *__restrict__ masks /* K x wps */,
                                                          const uint32_t *__restrict__ pop_n /* K */, uint32_t wps,
                                                          uint32_t G, uint32_t r, const uint32_t *__restrict__ weights /* nullable */,
                                                          uint64_t *__restrict__ out) {
     constexpr int NP = K * (K - 1) / 2;
+    constexpr int MU = 4;  // granules in flight per wave
+    extern __shared__ __attribute__((aligned(16))) uint32_t mk_lds[];  // K x wps4
     __shared__ uint64_t red[4][K + NP];
+    const uint32_t wps4 = (wps + 3) & ~3u;
+    for (uint32_t i = threadIdx.x; i < K * wps4; i += 256) {
+        const uint32_t k = i / wps4, j = i % wps4;
+        mk_lds[i] = j < wps ? masks[(uint64_t)k * wps + j] : 0u;
+    }
+    __syncthreads();
     const ScanTile t = tiles[blockIdx.x];
     const uint64_t b0 = t.site_begin >> 6, b1 = (t.site_end + 63) >> 6;
     const uint32_t lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -434,37 +448,115 @@ __global__ __launch_bounds__(256) void scan_multi_kernel(const uint32_t *__restr
 #pragma unroll
     for (int k = 0; k < K; ++k) nk[k] = pop_n[k];
     uint64_t acc[K + NP];
+    uint32_t s1[K], q2[K], px[NP > 0 ? NP : 1];
 #pragma unroll
     for (int i = 0; i < K + NP; ++i) acc[i] = 0;
-    for (uint64_t b = b0 + wave; b < b1; b += 4) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) { s1[k] = 0; q2[k] = 0; }
+#pragma unroll
+    for (int i = 0; i < NP; ++i) px[i] = 0;
+    const uint32_t Gf = r == 4 ? G : G - 1;  // full 16-byte granules (see scan_tiles_anyn_kernel)
+    auto load_batch = [&](const uint32_t *blk, uint32_t g, uint32_t nb, u32v4 (&v)[MU]) {
+#pragma unroll
+        for (int u = 0; u < MU; ++u)
+            if ((uint32_t)u < nb) v[u] = stream_load(reinterpret_cast<const u32v4 *>(blk + (uint64_t)(g + u) * 256 + lane * 4));
+    };
+    auto count_batch = [&](uint32_t g, uint32_t nb, const u32v4 (&v)[MU], uint32_t (&c)[K]) {
+#pragma unroll
+        for (int u = 0; u < MU; ++u)
+            if ((uint32_t)u < nb) {
+#pragma unroll
+                for (int k = 0; k < K; ++k) {
+                    const u32v4 m4 = *reinterpret_cast<const u32v4 *>(mk_lds + k * wps4 + 4 * (g + u));
+                    c[k] += __popc(v[u].x & m4.x) + __popc(v[u].y & m4.y) + __popc(v[u].z & m4.z) + __popc(v[u].w & m4.w);
+                }
+            }
+    };
+    // the last granule's r = 1..3 dwords per site (r == 4 counts as a full granule): loaded TOGETHER with the batch —
+    // read one by one behind it they cost three more memory latencies per block
+    auto load_tail = [&](const uint32_t *blk, uint32_t (&tl)[3]) {
+        const uint32_t *last = blk + (uint64_t)Gf * 256 + lane * r;
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+            if (Gf < G && (uint32_t)j < r) tl[j] = stream_load(last + j);
+    };
+    auto count_tail = [&](const uint32_t (&tl)[3], uint32_t (&c)[K]) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+            if (Gf < G && (uint32_t)j < r) {
+#pragma unroll
+                for (int k = 0; k < K; ++k) c[k] += __popc(tl[j] & mk_lds[k * wps4 + 4 * Gf + j]);
+            }
+    };
+    auto tally = [&](uint64_t b, const uint32_t (&c)[K]) {
+        const uint64_t s = b * 64 + lane;
+        if (s >= t.site_begin && s < t.site_end) {
+            if (SMALL) {
+                int pi = 0;
+#pragma unroll
+                for (int k = 0; k < K; ++k) {
+                    s1[k] += c[k];
+                    q2[k] += __umul24(c[k], c[k]);
+#pragma unroll
+                    for (int l = k + 1; l < K; ++l) px[pi++] += __umul24(c[k], c[l]);
+                }
+            } else {
+                const uint64_t wt = weights ? weights[s] : 1;  // wave-uniform choice
+                int pi = K;
+#pragma unroll
+                for (int k = 0; k < K; ++k) {
+                    acc[k] += wt * (c[k] * (nk[k] - c[k]));
+#pragma unroll
+                    for (int l = k + 1; l < K; ++l) acc[pi++] += wt * (c[k] * (nk[l] - c[l]) + c[l] * (nk[k] - c[k]));
+                }
+            }
+        }
+    };
+    uint64_t b = b0 + wave;
+    if (Gf <= (uint32_t)MU) {
+        // <= 512 haplotypes: a block is one batch; two blocks (up to 8 wave loads) in flight per wave
+        for (; b + 4 < b1; b += 8) {
+            const uint32_t *blk0 = sb + b * 64ull * wps, *blk1 = sb + (b + 4) * 64ull * wps;
+            u32v4 v0[MU], v1[MU];
+            uint32_t t0[3], t1[3];
+            load_batch(blk0, 0, Gf, v0);
+            load_tail(blk0, t0);
+            load_batch(blk1, 0, Gf, v1);
+            load_tail(blk1, t1);
+            uint32_t c0[K], c1[K];
+#pragma unroll
+            for (int k = 0; k < K; ++k) { c0[k] = 0; c1[k] = 0; }
+            count_batch(0, Gf, v0, c0);
+            count_tail(t0, c0);
+            tally(b, c0);
+            count_batch(0, Gf, v1, c1);
+            count_tail(t1, c1);
+            tally(b + 4, c1);
+        }
+    }
+    for (; b < b1; b += 4) {
         const uint32_t *blk = sb + b * 64ull * wps;
         uint32_t c[K];
 #pragma unroll
         for (int k = 0; k < K; ++k) c[k] = 0;
-        for (uint32_t g = 0; g + 1 < G; ++g) {
-            const u32v4 v = stream_load(reinterpret_cast<const u32v4 *>(blk + (uint64_t)g * 256 + lane * 4));
-#pragma unroll
-            for (int k = 0; k < K; ++k) {
-                const uint32_t *mk = masks + (uint64_t)k * wps + 4 * g;
-                c[k] += __popc(v.x & mk[0]) + __popc(v.y & mk[1]) + __popc(v.z & mk[2]) + __popc(v.w & mk[3]);
-            }
+        uint32_t tl[3];
+        load_tail(blk, tl);
+        for (uint32_t g = 0; g < Gf; g += MU) {
+            const uint32_t nb = Gf - g < (uint32_t)MU ? Gf - g : (uint32_t)MU;
+            u32v4 v[MU];
+            load_batch(blk, g, nb, v);
+            count_batch(g, nb, v, c);
         }
-        const uint32_t *last = blk + (uint64_t)(G - 1) * 256 + lane * r;
-        for (uint32_t j = 0; j < r; ++j) {
-            const uint32_t v = stream_load(last + j);
+        count_tail(tl, c);
+        tally(b, c);
+    }
+    if (SMALL) {
+        int pi = K;
 #pragma unroll
-            for (int k = 0; k < K; ++k) c[k] += __popc(v & masks[(uint64_t)k * wps + 4 * (G - 1) + j]);
-        }
-        const uint64_t s = b * 64 + lane;
-        if (s >= t.site_begin && s < t.site_end) {
-            const uint64_t wt = weights ? weights[s] : 1;  // wave-uniform choice
-            int pi = K;
+        for (int k = 0; k < K; ++k) {
+            acc[k] = (uint64_t)nk[k] * s1[k] - q2[k];
 #pragma unroll
-            for (int k = 0; k < K; ++k) {
-                acc[k] += wt * (c[k] * (nk[k] - c[k]));
-#pragma unroll
-                for (int l = k + 1; l < K; ++l) acc[pi++] += wt * (c[k] * (nk[l] - c[l]) + c[l] * (nk[k] - c[k]));
-            }
+            for (int l = k + 1; l < K; ++l) { acc[pi] = (uint64_t)nk[l] * s1[k] + (uint64_t)nk[k] * s1[l] - 2ull * px[pi - K]; ++pi; }
         }
     }
 #pragma unroll
@@ -961,10 +1053,19 @@ IMPOP_API int impop_site_counts(impop_ctx *ctx, const impop_matrix *m, const uin
 }
 
 template <int K>
-static void launch_multi(hipStream_t st, const impop_matrix *m, uint64_t n_tiles, const ScanTile *d_tiles, const uint32_t *d_masks,
-                         const uint32_t *d_n, uint64_t *d_parts) {
-    hipLaunchKernelGGL((scan_multi_kernel<K>), dim3((uint32_t)n_tiles), dim3(256), 0, st, m->d_sb, d_tiles, d_masks, d_n, m->g.wps,
-                       m->g.G, m->g.r, m->d_wt, d_parts);
+static int launch_multi(hipStream_t st, const impop_matrix *m, uint64_t n_tiles, const ScanTile *d_tiles, const uint32_t *d_masks,
+                        const uint32_t *d_n, uint64_t *d_parts, bool small) {
+    const size_t lds = (size_t)K * ((m->g.wps + 3) & ~3u) * 4;
+    if (small) {
+        hipLaunchKernelGGL((scan_multi_kernel<K, true>), dim3((uint32_t)n_tiles), dim3(256), lds, st, m->d_sb, d_tiles, d_masks, d_n,
+                           m->g.wps, m->g.G, m->g.r, m->d_wt, d_parts);
+    } else {
+        if (lds > 48 * 1024)
+            HIP_TRY(hipFuncSetAttribute((const void *)scan_multi_kernel<K, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL((scan_multi_kernel<K, false>), dim3((uint32_t)n_tiles), dim3(256), lds, st, m->d_sb, d_tiles, d_masks, d_n,
+                           m->g.wps, m->g.G, m->g.r, m->d_wt, d_parts);
+    }
+    return IMPOP_OK;
 }
 
 IMPOP_API int impop_scan_multi(impop_ctx *ctx, const impop_matrix *m, const impop_window *windows, uint64_t n_windows,
@@ -998,10 +1099,11 @@ IMPOP_API int impop_scan_multi(impop_ctx *ctx, const impop_matrix *m, const impo
     std::vector<ScanTile> tiles;
     std::vector<WinDesc> wd;
     uint64_t bytes = 0;
+    const uint32_t tile_blocks_used = default_tile_blocks(ctx, m, windows, n_windows);
     {
         std::vector<impop_window> mapped;
         map_windows(m, windows, n_windows, mapped);
-        build_tiles(mapped.data(), n_windows, default_tile_blocks(ctx, m, windows, n_windows), wps, tiles, wd, bytes);
+        build_tiles(mapped.data(), n_windows, tile_blocks_used, wps, tiles, wd, bytes);
         const int wrc = window_weights(m, windows, n_windows, wd);
         if (wrc) return wrc;
     }
@@ -1024,15 +1126,18 @@ IMPOP_API int impop_scan_multi(impop_ctx *ctx, const impop_matrix *m, const impo
         const ScanTile *dt = (const ScanTile *)(base + o_tiles);
         const uint32_t *dm = (const uint32_t *)(base + o_masks), *dn = (const uint32_t *)(base + o_n);
         uint64_t *dp = (uint64_t *)(base + o_parts);
+        // 32-bit per-lane partial sums: unweighted, <= 512 haplotypes, <= 1024 sites per lane and tile
+        const bool small = m->wt_prefix.empty() && n <= 512 && tile_blocks_used <= 4096;
         switch (K) {
-            case 2: launch_multi<2>(ctx->stream, m, nt, dt, dm, dn, dp); break;
-            case 3: launch_multi<3>(ctx->stream, m, nt, dt, dm, dn, dp); break;
-            case 4: launch_multi<4>(ctx->stream, m, nt, dt, dm, dn, dp); break;
-            case 5: launch_multi<5>(ctx->stream, m, nt, dt, dm, dn, dp); break;
-            case 6: launch_multi<6>(ctx->stream, m, nt, dt, dm, dn, dp); break;
-            case 7: launch_multi<7>(ctx->stream, m, nt, dt, dm, dn, dp); break;
-            default: launch_multi<8>(ctx->stream, m, nt, dt, dm, dn, dp); break;
+            case 2: rc = launch_multi<2>(ctx->stream, m, nt, dt, dm, dn, dp, small); break;
+            case 3: rc = launch_multi<3>(ctx->stream, m, nt, dt, dm, dn, dp, small); break;
+            case 4: rc = launch_multi<4>(ctx->stream, m, nt, dt, dm, dn, dp, small); break;
+            case 5: rc = launch_multi<5>(ctx->stream, m, nt, dt, dm, dn, dp, small); break;
+            case 6: rc = launch_multi<6>(ctx->stream, m, nt, dt, dm, dn, dp, small); break;
+            case 7: rc = launch_multi<7>(ctx->stream, m, nt, dt, dm, dn, dp, small); break;
+            default: rc = launch_multi<8>(ctx->stream, m, nt, dt, dm, dn, dp, small); break;
         }
+        if (rc) return rc;
         HIP_TRY(hipGetLastError());
     }
     const uint64_t items = n_windows * NP;

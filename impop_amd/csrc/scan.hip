@@ -397,6 +397,36 @@ __global__ __launch_bounds__(TPW == 1 ? 128 : 256) void scan_finalize_kernel(con
     if (sub == 0) window_epilogue(w, T, ps, taj, d_pi_mode, s_scope, out + i);
 }
 
+// c = sum_k popc(dword_k & mask_k) of site `lane` of a block: whole 16-byte granules (one coalesced 1 KiB wave load
+// each, all of them and the last granule's dwords issued before the first is consumed when G <= 5), masks wave-uniform
+__device__ __forceinline__ uint32_t masked_site_count(const uint32_t *__restrict__ blk, const uint32_t *__restrict__ mask, uint32_t G,
+                                                      uint32_t r, uint32_t lane) {
+    uint32_t c = 0;
+    const uint32_t Gf = r == 4 ? G : G - 1;
+    const uint32_t *last = blk + (uint64_t)Gf * 256 + lane * r;
+    uint32_t tl[3] = {0u, 0u, 0u};
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+        if (Gf < G && (uint32_t)j < r) tl[j] = stream_load(last + j);
+    for (uint32_t g = 0; g < Gf; g += 4) {
+        const uint32_t nb = Gf - g < 4u ? Gf - g : 4u;
+        u32v4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if ((uint32_t)u < nb) v[u] = stream_load(reinterpret_cast<const u32v4 *>(blk + (uint64_t)(g + u) * 256 + lane * 4));
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if ((uint32_t)u < nb) {
+                const uint32_t *m = mask + 4 * (g + u);
+                c += __popc(v[u].x & m[0]) + __popc(v[u].y & m[1]) + __popc(v[u].z & m[2]) + __popc(v[u].w & m[3]);
+            }
+    }
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+        if (Gf < G && (uint32_t)j < r) c += __popc(tl[j] & mask[4 * Gf + j]);
+    return c;
+}
+
 __global__ __launch_bounds__(256) void site_counts_kernel(const uint32_t *__restrict__ sb, const uint32_t *__restrict__ mask,
                                                           uint32_t wps, uint32_t G, uint32_t r, uint64_t site_begin,
                                                           uint64_t site_end, uint32_t *__restrict__ out) {
@@ -404,15 +434,7 @@ __global__ __launch_bounds__(256) void site_counts_kernel(const uint32_t *__rest
     const uint64_t b = (site_begin >> 6) + (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     const uint64_t s = b * 64 + lane;
     if (s < site_begin || s >= site_end) return;
-    const uint32_t *blk = sb + b * 64ull * wps;
-    uint32_t c = 0;
-    for (uint32_t k = 0; k < wps; ++k) {
-        const uint32_t g = k >> 2;
-        const uint32_t v = (g + 1 < G) ? blk[(uint64_t)g * 256 + lane * 4 + (k & 3)]
-                                       : blk[(uint64_t)(G - 1) * 256 + lane * r + (k - 4 * (G - 1))];
-        c += __popc(v & mask[k]);
-    }
-    out[s - site_begin] = c;
+    out[s - site_begin] = masked_site_count(sb + b * 64ull * wps, mask, G, r, lane);
 }
 
 // ---- K disjoint populations in one pass: all-pairs Hudson Fst (run_h_fst_panels.sh:60-71) -------
@@ -619,15 +641,7 @@ __global__ __launch_bounds__(256) void afs_kernel(const uint32_t *__restrict__ s
     for (uint64_t b = (c0 >> 6) + wave; b <= ((c1 - 1) >> 6); b += 4) {
         const uint64_t s = b * 64 + lane;
         if (s < c0 || s >= c1) continue;
-        const uint32_t *blk = sb + b * 64ull * wps;
-        uint32_t c = 0;
-        for (uint32_t k = 0; k < wps; ++k) {
-            const uint32_t g = k >> 2;
-            const uint32_t v = (g + 1 < G) ? blk[(uint64_t)g * 256 + lane * 4 + (k & 3)]
-                                           : blk[(uint64_t)(G - 1) * 256 + lane * r + (k - 4 * (G - 1))];
-            c += __popc(v & mask[k]);
-        }
-        atomicAdd(&hist[c], 1u);
+        atomicAdd(&hist[masked_site_count(sb + b * 64ull * wps, mask, G, r, lane)], 1u);
     }
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < bins; i += 256)

@@ -542,7 +542,7 @@ __device__ inline double hud_first_found(const SimView &S, const uint32_t *ia, c
     return __builtin_nan("");
 }
 // order_a / order_b (nullable): seed orders inside A / B as positions into ia / ib (see greedy_groups)
-// dynamic LDS: rowsum[max(ma,mb)] f64 (grouping scratch first) | grpA[ma] | szA[ma] | grpB[mb] | szB[mb]
+// dynamic LDS: rowsum[max(ma,mb)] f64 (grouping scratch first) | grpA[ma] | szA[ma] | repA[ma] | grpB[mb] | szB[mb] | repB[mb]
 __global__ __launch_bounds__(ST) void hud_grouped_kernel(SimBatch batch, const uint32_t *__restrict__ ia, uint32_t ma,
                                                          const uint32_t *__restrict__ ib, uint32_t mb,
                                                          const uint32_t *__restrict__ order_a,
@@ -552,18 +552,19 @@ __global__ __launch_bounds__(ST) void hud_grouped_kernel(SimBatch batch, const u
     const uint32_t mx = ma > mb ? ma : mb;
     double *rowsum = reinterpret_cast<double *>(lds_raw);
     uint32_t *grpA = reinterpret_cast<uint32_t *>(rowsum + mx);
-    uint32_t *szA = grpA + ma, *grpB = szA + ma, *szB = grpB + mb;
+    uint32_t *szA = grpA + ma, *repA = szA + ma, *grpB = repA + ma, *szB = grpB + mb, *repB = szB + mb;
     __shared__ double sh_res[3];
     __shared__ uint64_t sh_miss[3];
     const uint64_t prob = blockIdx.x;
     const SimView S = sim_view(batch, prob);
     const uint32_t tid = threadIdx.x;
-    const uint32_t GA = greedy_groups(S, ia, ma, threshold, order_a, grpA, szA, nullptr, reinterpret_cast<uint32_t *>(rowsum));
-    const uint32_t GB = greedy_groups(S, ib, mb, threshold, order_b, grpB, szB, nullptr, reinterpret_cast<uint32_t *>(rowsum));
+    const uint32_t GA = greedy_groups(S, ia, ma, threshold, order_a, grpA, szA, repA, reinterpret_cast<uint32_t *>(rowsum));
+    const uint32_t GB = greedy_groups(S, ib, mb, threshold, order_b, grpB, szB, repB, reinterpret_cast<uint32_t *>(rowsum));
     if (tid < 3) sh_miss[tid] = 0;
     __syncthreads();
     // within A, within B (hud.py:101-128), then between (hud.py:235-263): one pass each
     for (int pass = 0; pass < 3; ++pass) {
+        const uint32_t *r1 = pass == 1 ? repB : repA, *r2 = pass == 0 ? repA : repB;
         const uint32_t *i1 = pass == 1 ? ib : ia, *g1 = pass == 1 ? grpB : grpA, *s1 = pass == 1 ? szB : szA;
         const uint32_t *i2 = pass == 0 ? ia : ib, *g2 = pass == 0 ? grpA : grpB, *s2 = pass == 0 ? szA : szB;
         const uint32_t m1 = pass == 1 ? mb : ma, m2 = pass == 0 ? ma : mb;
@@ -572,7 +573,10 @@ __global__ __launch_bounds__(ST) void hud_grouped_kernel(SimBatch batch, const u
         for (uint32_t x = tid; x < G1; x += ST) {
             double acc = 0.0;
             for (uint32_t y = (pass == 2 ? 0 : x + 1); y < G2; ++y) {
-                const double sv = hud_first_found(S, i1, g1, m1, x, i2, g2, m2, y);
+                // the first pair the reference tries is (first member of g1, first member of g2): present on every Gram
+                // problem and almost always in a .sim table; only if it is absent, search on in sorted order
+                double sv = sim_get(S, i1[r1[x]], i2[r2[y]]);
+                if (sv != sv) sv = hud_first_found(S, i1, g1, m1, x, i2, g2, m2, y);
                 if (sv != sv) { ++miss; continue; }
                 if (pass == 2) acc += (((double)s1[x] * (double)s2[y]) / ((double)m1 * (double)m2)) * (1 - sv);  // :255-256
                 else acc += 2 * ((double)s1[x] / (double)m1) * ((double)s2[y] / (double)m2) * (1 - sv);        // :119-121
@@ -783,7 +787,7 @@ int launch_hud_grouped(impop_ctx *ctx, const SimBatch &b, uint64_t n_problems, c
                        double threshold, const uint64_t *d_seq_len, HfstOut *d_out) {
     if (!n_problems) return IMPOP_OK;
     REQUIRE(n_problems < 0x7FFFFFFFull, "grouped Fst: too many problems");
-    const size_t lds = (size_t)std::max(ma, mb) * 8 + ((size_t)ma + mb) * 8 + 16;
+    const size_t lds = (size_t)std::max(ma, mb) * 8 + ((size_t)ma + mb) * 12 + 16;
     REQUIRE(lds <= 150 * 1024, "grouped Fst: populations too large for the LDS-resident grouping");
     if (lds > 48 * 1024)
         HIP_TRY(hipFuncSetAttribute((const void *)hud_grouped_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -1093,7 +1097,7 @@ IMPOP_API int impop_fst_grouped_from_identity(impop_ctx *ctx, const double *iden
         if (in_b[i] && !ov) ib.push_back(i);
     }
     const uint32_t ma = (uint32_t)ia.size(), mb = (uint32_t)ib.size();
-    const size_t lds = (size_t)std::max(ma, mb) * 8 + ((size_t)ma + mb) * 8 + 16;
+    const size_t lds = (size_t)std::max(ma, mb) * 8 + ((size_t)ma + mb) * 12 + 16;
     REQUIRE(lds <= 150 * 1024, "grouped Fst: populations too large for the LDS-resident grouping");
     const size_t nn = (size_t)n * n;
     void *d = nullptr;

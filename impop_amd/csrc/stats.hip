@@ -715,7 +715,8 @@ int launch_pica2(impop_ctx *ctx, const SimBatch &b, uint64_t n_problems, const u
                  uint32_t *d_group_of) {
     if (!n_problems) return IMPOP_OK;
     const size_t lds = (size_t)n_el * (8 + 12) + (b.gram ? (size_t)b.n * 4 : 0) + 16;
-    REQUIRE(lds <= 150 * 1024, "pica2: %u elements exceed the LDS-resident grouping limit (7600; 6300 on Gram problems)", n_el);
+    // 160 KB per workgroup, of which ~10 KB are the kernel's static arrays (identity memo, scan counters)
+    REQUIRE(lds <= 148 * 1024, "pica2: %u elements exceed the LDS-resident grouping limit (7500; 6300 on Gram problems)", n_el);
     REQUIRE(n_problems < 0x7FFFFFFFull, "pica2: too many problems");
     // few large problems: Step 2 is split over row chunks (about 8 workgroups per CU in total, >= 16 rows each)
     uint32_t chunks = 1;

@@ -44,12 +44,53 @@ def from_paths_table(path: str) -> MatrixFile:
 _STEP = re.compile(r"([<>])([^<>]+)")
 
 
-def from_gfa(path: str, ref_prefix: Optional[str] = None, expand_bp: bool = True) -> MatrixFile:
+def _from_gfa_native(path: str, ref_prefix: Optional[str]) -> Optional[MatrixFile]:
+    """Node-level extraction through the native parser in libimpop_hip.so (impop_gfa_parse: one mmap pass, bits packed
+    directly — no dense byte matrix, no Python step lists).  None on ANY non-zero status: the Python code below then
+    handles the file and raises whatever it raises."""
+    import ctypes as C
+    import os
+
+    from . import _lib
+    lib = _lib.load()
+    h = C.c_void_p()
+    if lib.impop_gfa_parse(os.fsencode(path), None if ref_prefix is None else ref_prefix.encode(), C.byref(h)) != 0:
+        return None
+    try:
+        n, n_seg, nb, ref_row = C.c_uint32(), C.c_uint64(), C.c_uint64(), C.c_int64()
+        _lib.check(lib.impop_gfa_info(h, C.byref(n), C.byref(n_seg), C.byref(nb), C.byref(ref_row)))
+        buf = C.create_string_buffer(max(nb.value, 1))
+        _lib.check(lib.impop_gfa_names(h, buf))
+        names = [x.decode("utf-8", "surrogateescape") for x in buf.raw[: nb.value].split(b"\0")[: n.value]]
+        words = max((n_seg.value + 63) // 64, 1)
+        bits = np.zeros((n.value, words), dtype=np.uint64)
+        _lib.check(lib.impop_gfa_bits(h, bits.ctypes.data_as(C.POINTER(C.c_uint64)), words))
+        lens = np.zeros(n_seg.value, dtype=np.uint32)
+        _lib.check(lib.impop_gfa_lengths(h, lens.ctypes.data_as(C.POINTER(C.c_uint32))))
+        mf = MatrixFile(bits=bits, n_site=int(n_seg.value), names=names)
+        mf.site_weight = lens
+        if ref_prefix is not None:
+            pos = np.zeros(n_seg.value, dtype=np.int64)
+            _lib.check(lib.impop_gfa_positions(h, pos.ctypes.data_as(C.POINTER(C.c_int64))))
+            mf.site_pos = pos
+            mf.contig = ref_prefix or ""
+        return mf
+    finally:
+        lib.impop_gfa_free(h)
+
+
+def from_gfa(path: str, ref_prefix: Optional[str] = None, expand_bp: bool = True, native: bool = True) -> MatrixFile:
     """GFA 1.x: S (segments), P (paths, `id+,id-,...`) and W (walks, `>id<id...`) lines.
     Rows = paths/walks (W names become PanSN `sample#hap#seqid[:start-end]`), columns = segments in
     numeric-id order (odgi sort order), optionally expanded to bp columns.  If `ref_prefix` names a
     path (prefix match, e.g. 'CHM13#0#'), site_pos holds each column's coordinate on it (columns
-    off the reference inherit the coordinate of the preceding reference column)."""
+    off the reference inherit the coordinate of the preceding reference column).
+    Node-level extraction (expand_bp=False, the scalable form: node lengths become site weights) goes through the
+    native parser when it accepts the file; this function is the definition and the fallback."""
+    if not expand_bp and native:
+        mf = _from_gfa_native(path, ref_prefix)
+        if mf is not None:
+            return mf
     seg_len: Dict[str, int] = {}
     paths: List[Tuple[str, List[str]]] = []
     ref_start = 0

@@ -393,6 +393,23 @@ int impop_sim_bad_text(const impop_sim *s, char *buf, size_t buflen);
 int impop_sim_dense(const impop_sim *s, double *out);        /* n x n, sorted-name order, NaN = absent */
 int impop_sim_free(impop_sim *s);
 
+/* ---- native GFA ingest (host code) ---------------------------------------------
+ * S / P / W lines of the window graph (`impg query -o gfa`, run_tajd.sh:126; `odgi view -g`, :140) -> the NODE-level
+ * presence matrix: rows = paths and walks sorted by name (W named sample#hap#seqid[:start-end]), columns = segments
+ * (decimal ids in numeric order, then the others), bit-packed hap-major as impop_matrix_upload takes it; the segment
+ * lengths are the site weights of impop_matrix_set_site_weights.  ref_prefix (nullable): the first path whose name
+ * starts with it gives every column a reference coordinate (start parsed from a trailing ":start-end"; columns off
+ * the reference inherit the preceding one; non-decreasing).  Same rules as impop_amd/extract.py:from_gfa
+ * (expand_bp=False), which the caller falls back to on ANY non-zero status (so error texts stay Python's). */
+typedef struct impop_gfa impop_gfa;
+int impop_gfa_parse(const char *path, const char *ref_prefix, impop_gfa **out);
+int impop_gfa_info(const impop_gfa *g, uint32_t *n_path, uint64_t *n_seg, uint64_t *names_bytes, int64_t *ref_row);
+int impop_gfa_names(const impop_gfa *g, char *buf);                       /* NUL-separated, row order */
+int impop_gfa_bits(const impop_gfa *g, uint64_t *bits_hap_major, uint64_t row_stride_words);
+int impop_gfa_lengths(const impop_gfa *g, uint32_t *lengths);            /* per column */
+int impop_gfa_positions(const impop_gfa *g, int64_t *positions);         /* per column; needs ref_prefix */
+int impop_gfa_free(impop_gfa *g);
+
 /* CPython round(x, ndigits) (pica2.py:83, h-fst.py:150) evaluated on the GPU,
  * exposed so that the device implementation can be fuzzed against CPython. */
 int impop_py_round(impop_ctx *ctx, const double *x, uint64_t count, int ndigits, double *out);

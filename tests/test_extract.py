@@ -1,5 +1,7 @@
 """CPU: presence-matrix extractors and the matrix container (SURVEY §8f-2/3 host side)."""
 
+import numpy as np
+
 import impop_amd
 from impop_amd import extract, matrixio
 
@@ -49,3 +51,76 @@ def test_from_paths_table(tmp_path):
     assert mf.names == ["a#1#x", "b#1#x"]
     assert impop_amd.unpack_hap_major(mf.bits, 3).tolist() == [[1, 1, 1], [1, 0, 1]]
     assert mf.site_range(1, 3) == (1, 3)
+
+
+def _random_gfa(rng, n_seg, n_path, numeric=True, walks=True):
+    ids = [str(int(x)) for x in rng.choice(np.arange(1, 10 * n_seg), size=n_seg, replace=False)] if numeric else \
+          [f"s{int(x)}" if rng.random() < 0.5 else str(int(x)) for x in rng.choice(np.arange(1, 10 * n_seg), size=n_seg, replace=False)]
+    lines = ["H\tVN:Z:1.1"]
+    for i in ids:
+        L = int(rng.integers(1, 30))
+        k = rng.random()
+        if k < 0.6:
+            lines.append(f"S\t{i}\t{'ACGT' * 8}"[: len(f"S\t{i}\t") + L])
+        elif k < 0.8:
+            lines.append(f"S\t{i}\t*\tLN:i:{L}")
+        else:
+            lines.append(f"S\t{i}\t{'A' * 3}\tXX:Z:foo\tLN:i:{L}\tLN:i:{L + 2}")   # the last LN tag wins
+    if rng.random() < 0.5:
+        lines.append(f"S\t{ids[0]}\t{'C' * 7}")  # a repeated id: later line overwrites the length, keeps the first position
+    names = []
+    for r in range(n_path):
+        steps = [ids[int(j)] for j in np.sort(rng.choice(n_seg, size=int(rng.integers(1, n_seg + 1)), replace=False))]
+        if rng.random() < 0.3:
+            steps = steps + steps[: 2]   # revisits
+        if walks and rng.random() < 0.4:
+            w = "".join((">" if rng.random() < 0.7 else "<") + s for s in steps)
+            coords = ("0", str(len(steps))) if rng.random() < 0.7 else ("*", "*")
+            lines.append(f"W\tHG{r:03d}\t{int(rng.integers(1, 3))}\tctg{r}\t{coords[0]}\t{coords[1]}\t{w}")
+        else:
+            nm = f"HG{int(rng.integers(0, n_path)):03d}#{int(rng.integers(1, 3))}#c{r}:{int(rng.integers(0, 50))}-{int(rng.integers(50, 99))}"
+            lines.append(f"P\t{nm}\t" + ",".join(s + ("+" if rng.random() < 0.7 else "-") for s in steps) + "\t*")
+            names.append(nm)
+    rng.shuffle(lines[1:])  # S / P / W lines in any order
+    return "\n".join(lines) + "\n", names
+
+
+def test_native_gfa_parser_equals_python_extractor(tmp_path):
+    """impop_gfa_parse (host C++ in libimpop_hip.so) against extract.from_gfa(native=False), the definition: names, packed
+    bits, node lengths (site weights) and reference coordinates on random graphs — numeric and mixed ids, P and W lines in
+    any order, revisited and repeated segments, several LN tags — and the fall-back on files the parser declines."""
+    import numpy as np
+    rng = np.random.default_rng(3)
+    for trial in range(40):
+        text, pnames = _random_gfa(rng, int(rng.integers(1, 200)), int(rng.integers(1, 12)), numeric=trial % 3 != 0)
+        p = tmp_path / f"g{trial}.gfa"
+        p.write_text(text)
+        ref = None
+        if pnames and trial % 2 == 0:
+            ref = sorted(pnames)[0].split(":")[0][:6]
+        want = extract.from_gfa(str(p), ref_prefix=ref, expand_bp=False, native=False)
+        got = extract._from_gfa_native(str(p), ref)
+        assert got is not None, trial
+        assert got.names == want.names and got.n_site == want.n_site
+        assert (got.bits == want.bits).all()
+        assert (got.site_weight == want.site_weight).all() and got.site_weight.dtype == want.site_weight.dtype
+        if ref is None:
+            assert got.site_pos is None and want.site_pos is None
+        else:
+            assert (got.site_pos == want.site_pos).all() and got.contig == want.contig
+        assert (extract.from_gfa(str(p), ref_prefix=ref, expand_bp=False).bits == want.bits).all()   # the default path
+    # declined / failing inputs fall back to the Python reader, whose errors are the interface
+    bad = tmp_path / "bad.gfa"
+    bad.write_text("S\t1\tACGT\nP\tx\t1+,2+\t*\n")                       # a step on a segment without S line
+    assert extract._from_gfa_native(str(bad), None) is None
+    import pytest
+    with pytest.raises(KeyError):
+        extract.from_gfa(str(bad), expand_bp=False)
+    crlf = tmp_path / "crlf.gfa"
+    crlf.write_bytes(b"S\t1\tACGT\r\nP\tx\t1+\t*\r\n")
+    assert extract._from_gfa_native(str(crlf), None) is None
+    assert extract._from_gfa_native(str(tmp_path / "t.gfa"), "NOPE#") is None if (tmp_path / "t.gfa").exists() else True
+    (tmp_path / "t2.gfa").write_text(GFA)
+    assert extract._from_gfa_native(str(tmp_path / "t2.gfa"), "NOPE#") is None
+    with pytest.raises(ValueError):
+        extract.from_gfa(str(tmp_path / "t2.gfa"), ref_prefix="NOPE#", expand_bp=False)

@@ -258,6 +258,15 @@ __global__ __launch_bounds__(256, 4) void scan_tiles_anyn_kernel(const uint32_t 
     for (uint64_t b = b0 + wave; b < b1; b += 4) {
         const uint32_t *blk = sb + b * 64ull * wps + lane * 4;
         uint32_t c = 0, cP = 0, cA = 0, cB = 0;
+        // the last granule's r = 1..3 dwords per site go out first, together with the first batch (read behind the
+        // batches they cost one more memory latency per block)
+        uint32_t tail[3] = {0u, 0u, 0u};
+        if (Gf < G) {
+            const uint32_t *last = sb + b * 64ull * wps + (uint64_t)Gf * 256 + lane * r;
+#pragma unroll
+            for (int e = 0; e < 3; ++e)
+                if ((uint32_t)e < r) tail[e] = stream_load(last + e);
+        }
         // full batches of AN_U granules (all loads out first, consumed with staggered waits) ...
         uint32_t g = 0;
         for (; g + AN_U <= Gf; g += AN_U) {
@@ -280,11 +289,6 @@ __global__ __launch_bounds__(256, 4) void scan_tiles_anyn_kernel(const uint32_t 
                 if ((uint32_t)u < nb) anyn_granule<SUBSET_P>(v[u], lp, la, lb, g + u, c, cP, cA, cB);
         }
         if (Gf < G) {
-            const uint32_t *last = sb + b * 64ull * wps + (uint64_t)Gf * 256 + lane * r;
-            uint32_t tail[3] = {0u, 0u, 0u};
-#pragma unroll
-            for (int e = 0; e < 3; ++e)
-                if ((uint32_t)e < r) tail[e] = stream_load(last + e);
 #pragma unroll
             for (int e = 0; e < 3; ++e)
                 if ((uint32_t)e < r) {

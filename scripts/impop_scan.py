@@ -82,6 +82,11 @@ def main():
     ap.add_argument("--compact", action="store_true", help="scan from the matrix compacted to its variable sites "
                     "(impop_matrix_compact): identical output, far fewer bytes (and, on the all-pairs path, multiply-adds) per pass")
     ap.add_argument("--device", type=int, default=None, help="default: LOCAL_RANK, else 0")
+    ap.add_argument("--devices", type=int, default=1, metavar="N",
+                    help="ONE process driving N GPUs through the C ABI (impop_scan_sharded): the BED rows are cut into N contiguous "
+                         "ranges, each device holds the slab of sites its rows touch, every pass is launched before the first "
+                         "result is fetched; no torch, no launcher.  With fewer than N devices the contexts share device 0. "
+                         "Streaming scan only (not with --panel, --compact or the all-pairs formats)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend when launched with WORLD_SIZE > 1 "
                     "(nccl = RCCL over xGMI; gloo for rehearsals)")
     args = ap.parse_args()
@@ -113,11 +118,21 @@ def main():
         regions.append(region)
     out = (open(args.output, "w") if args.output else sys.stdout) if rank == 0 else open(os.devnull, "w")
     ctx = impop_amd.Context(args.device)
+    if args.devices > 1 and (world > 1 or args.panel or args.compact):
+        print("Error: --devices N is the one-process form: not under torch.distributed.run, not with --panel / --compact", file=sys.stderr)
+        sys.exit(2)
     grouped_fst = args.format == "hfst" and args.fst_method == "grouped"
     need_pairwise = grouped_fst or (args.format == "pica2" and ((args.threshold is not None and args.threshold < 1.0)
                                                                  or args.round_digits is not None or args.identity != "match"))
+    if args.devices > 1 and need_pairwise:
+        print("Error: --devices N serves the streaming scan; the all-pairs formats (thresholded / rounded pica2, grouped Fst) run "
+              "on one device or under torch.distributed.run", file=sys.stderr)
+        sys.exit(2)
+    multi_dev = args.devices > 1
     all_wins = impop_amd.make_windows(wins)
-    if world > 1:
+    if multi_dev:
+        bm = None  # every device gets only its slab, further down
+    elif world > 1:
         from impop_amd.distributed import shard_windows
         loc, s0, s1, _ = shard_windows(all_wins, world, rank)
         w0, w1 = s0 // 64, (s1 + 63) // 64  # slab = whole 64-bit words of the hap-major rows
@@ -197,6 +212,25 @@ def main():
         # the pica2 / hfst tables print neither S nor D: s_scope 2 skips the site scan of the all-pairs path
         res = bm.pairwise_scan(wins, mask_p, mask_a, mask_b, kind=args.identity, threshold=thr, round_digits=args.round_digits,
                                s_scope=2, fst_method=args.fst_method if grouped_fst else "direct")
+    elif multi_dev:
+        # one process, several devices: a context + the slab of its BED rows per device (impop_shard_windows says which)
+        from impop_amd import engine
+        import ctypes as C
+        n_dev = C.c_int(0)
+        impop_amd._lib.load().impop_device_count(C.byref(n_dev))
+        ctxs, slabs, begins = [], [], []
+        for k in range(args.devices):
+            first, cnt, s0, s1 = engine.shard_windows_c(all_wins, args.devices, k)
+            w0, w1 = s0 // 64, max((s1 + 63) // 64, s0 // 64 + 1)
+            ck = impop_amd.Context(k if n_dev.value >= args.devices else 0)
+            n_slab = max(min(mf.n_site, 64 * w1) - 64 * w0, 0)
+            sk = ck.upload(np.ascontiguousarray(mf.bits[:, w0:w1]), n_slab, keep_hap_major=False)
+            if mf.site_weight is not None:
+                sk.set_site_weights(mf.site_weight[64 * w0: 64 * w0 + n_slab])
+            ctxs.append(ck); slabs.append(sk); begins.append(64 * w0)
+        res = engine.scan_sharded(slabs, begins, all_wins, mask_p, mask_a, mask_b)
+        for sk, ck in zip(slabs, ctxs):
+            sk.free(); ck.close()
     else:
         res = bm.scan(wins, mask_p, mask_a, mask_b)
     if world > 1:
@@ -256,7 +290,8 @@ def main():
             print(f"{reg}\t{L}\t{sample_count}\t{int(r['s_all'])}\t{float(r['pi_site']):.8f}\t{taj}", file=out)
     if args.output or rank != 0:
         out.close()
-    bm.free()
+    if bm is not None:
+        bm.free()
     ctx.close()
     if world > 1:
         import torch.distributed as dist

@@ -176,6 +176,13 @@ def test_batch_driver_two_ranks_equal_one(tmp_path):
                          capture_output=True, text=True)
     assert two.returncode == 0, two.stderr[-2000:]
     assert open(tmp_path / "two.tsv").read() == one.stdout
+    # ONE process driving several contexts through the C ABI (impop_scan_sharded; the contexts share the box's one GPU)
+    for nd in (2, 3):
+        many = subprocess.run([sys.executable] + base + ["--devices", str(nd)], capture_output=True, text=True)
+        assert many.returncode == 0, many.stderr
+        assert many.stdout == one.stdout, nd
+    bad = subprocess.run([sys.executable] + base + ["--devices", "2", "--compact"], capture_output=True, text=True)
+    assert bad.returncode == 2 and "--devices N" in bad.stderr
     # the K-population panel (all pairs per window) sharded the same way
     (tmp_path / "C.txt").write_text("\n".join(f"S{i:03d}" for i in range(15, 20)) + "\n")
     panel = [os.path.join(ROOT, "scripts", "impop_scan.py"), "--matrix", str(tmp_path / "m.npz"), "--bed", str(tmp_path / "w.bed"),

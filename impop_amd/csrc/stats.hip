@@ -60,9 +60,316 @@ __device__ inline int64_t match_cutoff(const SimView &S, double thr) {
     return lo;
 }
 
+// ---------------------------------------------------------------------------------------
+// Greedy grouping on bits (seeds in position order).  Whether o joins seed i does not depend on the state of the
+// grouping — only whether o is still free does.  So the join tests of a BLOCK of candidate seeds (the next free
+// positions) are made together, one bit each, and the reference's loop (pica2.py:94-112) then runs on those bits in one
+// wave, without a barrier or a memory round trip per group (the serial loop of greedy_groups pays both: 2.5 us per
+// group at 465 elements, 6 us at 4096 — 25 ms for 4096 singleton groups, 100 of the 144 ms of config 5).
+// Seeds ascend, so everything below a seed is already grouped and only o > seed is tested: the upper triangle, the part
+// the Gram kernel writes, read along rows.
+// Bit layout: position o is bit (o % 256) / 4 of word 4 (o / 256) + o % 4.  A wave covers 256 consecutive positions of a
+// row with ONE 16-byte load per lane (lane L: positions 4L .. 4L+3) and its four ballots ARE the four words of that
+// 256-block.  aw = 4 ceil(m / 256) words per row.
+// Where the bits come from:
+//  * FROM_ADJ: pica2_adj_kernel (grid: problems x row chunks) has tested ALL pairs o > i of a large problem up front,
+//    over the whole chip; a block is up to 64 rows of that matrix, fetched in one batch;
+//  * otherwise the workgroup tests the block's pairs itself — (candidate, 256-block) items dealt to the waves, JU in
+//    flight per lane — with blocks just long enough to fill two such batches per wave.
+// Measured (tools/time_epilogue.py, 4096 x 465-haplotype 10 kb windows; tools/bench_config5.py): config 5 (4096
+// haplotypes, 200 x 50 kb windows, singleton-heavy) 144 -> 53 ms end to end; at 465 haplotypes the grouping of 465
+// singleton groups 985 -> 600 us per problem (pica2_kernel 6.9 -> 5.0 ms per 4096 windows), 8 groups 38 -> 32 us.  What is
+// left at 465 is wave 0's share of a SIMD it shares with four other problems' waves, not barriers or round trips.
+// Then wave 0, the free set in its registers (lane l holds words l and l + 64), walks the block's candidates in order: a
+// candidate an earlier seed of the block absorbed is skipped, any other opens a group of itself plus (its row AND the
+// free set).  All threads call; returns the number of groups; m <= 8192.
+struct Pica2Split {
+    uint32_t *tab;     // problem p: rep[n_el] | gsz[n_el] | G | have | npairs lo | npairs hi
+    double *rowsum;    // problem p: n_el doubles
+    uint64_t *adj;     // nullable; problem p: n_el rows of 4 ceil(n_el / 256) words (layout above): "o > i and o joins seed i"
+};
+__device__ inline uint32_t *split_tab(const Pica2Split &sp, uint64_t p, uint32_t n_el) { return sp.tab + p * (2ull * n_el + 4); }
+
+__host__ __device__ inline uint32_t bit_words(uint32_t m) { return 4 * ((m + 255) / 256); }
+__device__ inline uint32_t bit_word(uint32_t o) { return 4 * (o >> 8) + (o & 3); }
+__device__ inline uint32_t bit_lane(uint32_t o) { return (o & 255) >> 2; }
+__device__ inline uint32_t bit_pos(uint32_t w, uint32_t L) { return 256 * (w >> 2) + 4 * L + (w & 3); }
+__device__ inline uint64_t readlane_u64(uint64_t v, uint32_t l /*uniform*/) {
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, (int)l);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), (int)l);
+    return ((uint64_t)hi << 32) | lo;
+}
+
+struct JoinTest {  // "identity(seed, o) > threshold", as greedy_groups tests it
+    bool by_cutoff;  // Gram + match: H <= H* (match_cutoff)
+    bool vec;        // Gram problem whose rows can be read as aligned quads at the positions themselves
+    int64_t hstar;
+    double thr;
+};
+__device__ inline JoinTest join_test(const SimView &S, const uint32_t *idx, double thr) {
+    JoinTest t;
+    t.by_cutoff = S.gram && S.kind == IMPOP_IDENTITY_MATCH;
+    t.hstar = t.by_cutoff ? match_cutoff(S, thr) : 0;
+    t.thr = thr;
+    t.vec = S.gram && !idx && (S.ld & 3u) == 0 && (S.seg_stride & 3ull) == 0 && ((uintptr_t)S.gram & 15) == 0;
+    return t;
+}
+typedef int i32q __attribute__((ext_vector_type(4)));
+// word `k` (0..3, varying by lane) of four uniform words, without indexing a register array by a lane value
+__device__ inline uint64_t pick4(const uint64_t (&w)[4], uint32_t k) { return k == 0 ? w[0] : k == 1 ? w[1] : k == 2 ? w[2] : w[3]; }
+
+// the four words of 256-block hs[k] of candidate cs[k]'s row, for U items (live[k] false = nothing to do): all loads of
+// the U items go out before the first is consumed.  Registers decide how many problems a CU holds at once, so only what
+// must wait for memory is kept per item: the shared counts I (the two diagonal entries come from LDS when the bit is
+// formed) or the identities.
+template <int U>
+__device__ inline void join_blocks(const SimView &S, const JoinTest &T, const uint32_t *__restrict__ idx, uint32_t m,
+                                   const uint32_t (&cs)[U], const uint32_t (&hs)[U], const bool (&live)[U], uint64_t (&bits)[U][4]) {
+    const uint32_t lane = threadIdx.x & 63;
+    if (S.gram) {
+        i32q iv[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint32_t o = 256 * hs[u] + 4 * lane;
+            iv[u] = i32q{0, 0, 0, 0};
+            if (!live[u] || o + 3 <= cs[u] || o >= m) continue;  // no position of the quad is above the seed and in range
+            if (T.vec) {
+                const int32_t *g = S.gram + (uint64_t)cs[u] * S.ld + o;  // o + 3 < ld: ld is a multiple of 4 and o < m <= ld
+                i32q v = *reinterpret_cast<const i32q *>(g);
+                for (uint32_t k = 1; k < S.nseg; ++k) v += *reinterpret_cast<const i32q *>(g + k * S.seg_stride);
+                iv[u] = v + (int32_t)S.add;
+            } else {
+                const uint32_t es = idx ? idx[cs[u]] : cs[u];
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (o + j > cs[u] && o + j < m) iv[u][j] = (int32_t)gram_at(S, es, idx ? idx[o + j] : o + j);  // positions ascend, so do the elements
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint32_t es = idx ? idx[cs[u] < m ? cs[u] : 0] : cs[u];
+            const int64_t as = live[u] ? (S.diag ? (int64_t)S.diag[es] : gram_at(S, es, es)) : 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t o = 256 * hs[u] + 4 * lane + j;
+                bool joins = false;
+                if (live[u] && o > cs[u] && o < m) {
+                    const uint32_t eo = idx ? idx[o] : o;
+                    const int64_t ao = S.diag ? (int64_t)S.diag[eo] : gram_at(S, eo, eo);
+                    if (T.by_cutoff) {
+                        joins = as + ao - 2 * (int64_t)iv[u][j] <= T.hstar;
+                    } else {
+                        const double v = sim_from_gram(S, (int64_t)iv[u][j], as, ao);
+                        joins = v == v && v > T.thr;
+                    }
+                }
+                bits[u][j] = __ballot(joins);
+            }
+        }
+    } else {
+        // dense identities (the .sim path: one problem per call): eight loads in flight are enough, two items at a time
+        static_assert(U % 2 == 0, "items in pairs");
+#pragma unroll
+        for (int u0 = 0; u0 < U; u0 += 2) {
+            double sv[2][4];
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const uint32_t o = 256 * hs[u0 + k] + 4 * lane + j;
+                    sv[k][j] = 0.0;
+                    if (live[u0 + k] && o > cs[u0 + k] && o < m) sv[k][j] = sim_get(S, idx ? idx[cs[u0 + k]] : cs[u0 + k], idx ? idx[o] : o);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const uint32_t o = 256 * hs[u0 + k] + 4 * lane + j;
+                    const bool in = live[u0 + k] && o > cs[u0 + k] && o < m;
+                    bits[u0 + k][j] = __ballot(in && sv[k][j] == sv[k][j] && sv[k][j] > T.thr);  // strict > (pica2.py:106, hud.py:80)
+                }
+            }
+        }
+    }
+}
+
+// dynamic LDS: diag[batch.n] int32 (Gram problems)
+__global__ __launch_bounds__(ST) void pica2_adj_kernel(SimBatch batch, const uint32_t *__restrict__ idx, uint32_t n_el,
+                                                       double threshold, Pica2Split split) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    const uint64_t prob = blockIdx.x;
+    SimView S = sim_view(batch, prob);
+    const uint32_t tid = threadIdx.x, lane = tid & 63;
+    if (S.gram) {
+        int32_t *diag_l = reinterpret_cast<int32_t *>(lds_raw);
+        for (uint32_t i = tid; i < batch.n; i += ST) diag_l[i] = (int32_t)gram_at(S, i, i);
+        S.diag = diag_l;
+    }
+    const JoinTest T = join_test(S, idx, threshold);
+    __syncthreads();
+    const uint32_t aw = bit_words(n_el), nh = aw / 4;
+    uint64_t *adj = split.adj + prob * (uint64_t)n_el * aw;
+    constexpr int AU = 4;
+    for (uint32_t i = (tid >> 6) + (ST / 64) * blockIdx.y; i < n_el; i += (ST / 64) * gridDim.y) {
+        for (uint32_t h0 = i >> 8; h0 < nh; h0 += AU) {
+            uint32_t cs[AU], hs[AU];
+            bool live[AU];
+            uint64_t bits[AU][4];
+#pragma unroll
+            for (int u = 0; u < AU; ++u) { cs[u] = i; hs[u] = h0 + u; live[u] = h0 + u < nh; }
+            join_blocks<AU>(S, T, idx, n_el, cs, hs, live, bits);
+#pragma unroll
+            for (int u = 0; u < AU; ++u)
+                if (lane < 4 && live[u]) adj[(uint64_t)i * aw + 4 * (h0 + u) + lane] = pick4(bits[u], lane);
+        }
+    }
+}
+
+template <bool FROM_ADJ>
+__device__ inline uint32_t greedy_groups_bits(const uint64_t *__restrict__ adj, const SimView &S, const uint32_t *__restrict__ idx,
+                                              double thr, uint32_t m, uint32_t *grp, uint32_t *gsz, uint32_t *rep, uint64_t *rows_big) {
+    constexpr int JU = 4;               // (candidate, 256-block) items in flight per wave
+    constexpr uint32_t ROWS_S = 512;    // words of candidate rows a small problem's block may take
+    __shared__ uint32_t cand[64];
+    __shared__ uint32_t sh_n, sh_G;
+    __shared__ uint64_t rows_small[FROM_ADJ ? 1 : ROWS_S];
+    if (m == 0) return 0;
+    const uint32_t tid = threadIdx.x, lane = tid & 63;
+    const uint32_t aw = bit_words(m), nh = aw / 4;
+    uint64_t *rows = FROM_ADJ ? rows_big : rows_small;  // rows_big: m words (the caller's scratch)
+    uint32_t B;
+    if (FROM_ADJ) {
+        B = m / aw < 64 ? m / aw : 64;
+    } else {
+        const uint32_t cap = ROWS_S / aw < 64 ? ROWS_S / aw : 64;      // >= 4: aw <= 128
+        const uint32_t fill = (2 * (ST / 64) * JU + nh - 1) / nh;      // candidates whose blocks make two batches per wave
+        B = fill < 4 ? 4 : fill;
+        if (B > cap) B = cap;
+    }
+    const JoinTest T = FROM_ADJ ? JoinTest{false, false, 0, 0.0} : join_test(S, idx, thr);
+    for (uint32_t i = tid; i < m; i += ST) { grp[i] = NONE; gsz[i] = 0; }
+    auto initial = [&](uint32_t w) -> uint64_t {  // bit L of word w: position bit_pos(w, L) < m
+        const uint32_t base = 256 * (w >> 2) + (w & 3);
+        if (w >= aw || m <= base) return 0;
+        const uint32_t c = (m - base + 3) / 4;
+        return c >= 64 ? ~0ull : ((1ull << c) - 1);
+    };
+    uint64_t u0 = initial(lane), u1 = initial(lane + 64);  // the free set (wave 0's copy is the one that counts)
+    uint32_t G = 0, h_first = 0;
+    __syncthreads();
+    for (;;) {
+        uint32_t mycand = 0;  // wave 0: lane b holds candidate b
+        if (tid < 64) {  // the next up-to-B free positions, ascending: uniform work on words read across the lanes
+            uint32_t n = 0;
+            bool first = true;
+            // (h_first lives across the workgroup-wide loop in a vector register: tell the compiler it is one value per wave,
+            // or every readlane below turns into a loop over lanes)
+            for (uint32_t h = __builtin_amdgcn_readfirstlane(h_first); h < nh && n < B; ++h) {
+                uint64_t w[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) w[j] = readlane_u64(4 * h + j < 64 ? u0 : u1, (4 * h + j) & 63);
+                uint64_t any = w[0] | w[1] | w[2] | w[3];
+                if (any && first) { h_first = h; first = false; }
+                while (any && n < B) {
+                    const uint32_t L = (uint32_t)__ffsll((unsigned long long)any) - 1;
+                    any &= any - 1;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (((w[j] >> L) & 1) && n < B) {
+                            if (lane == n) mycand = 256 * h + 4 * L + j;
+                            ++n;
+                        }
+                }
+            }
+            if (lane < n) cand[lane] = mycand;
+            if (lane == 0) sh_n = n;
+        }
+        __syncthreads();
+        const uint32_t n = __builtin_amdgcn_readfirstlane(sh_n);
+        if (n == 0) break;
+        if (FROM_ADJ) {
+            constexpr int RU = 8;  // candidate rows in flight per wave
+            for (uint32_t b0 = tid >> 6; b0 < n; b0 += (ST / 64) * RU) {
+                uint64_t v[RU][2];
+#pragma unroll
+                for (int u = 0; u < RU; ++u) {
+                    const uint32_t b = b0 + (ST / 64) * u;
+#pragma unroll
+                    for (int hh = 0; hh < 2; ++hh) {
+                        const uint32_t w = lane + 64 * hh;
+                        v[u][hh] = 0;
+                        if (b < n && w < aw && w >= 4 * (cand[b] >> 8)) v[u][hh] = adj[(uint64_t)cand[b] * aw + w];
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < RU; ++u) {
+                    const uint32_t b = b0 + (ST / 64) * u;
+#pragma unroll
+                    for (int hh = 0; hh < 2; ++hh) {
+                        const uint32_t w = lane + 64 * hh;
+                        if (b < n && w < aw) rows[(uint64_t)b * aw + w] = v[u][hh];
+                    }
+                }
+            }
+        } else {
+            const uint32_t items = n * nh;  // item = (candidate b, block h): rows[b * aw + 4 h .. + 4]
+            for (uint32_t it0 = (tid >> 6) * JU; it0 < items; it0 += (ST / 64) * JU) {
+                uint32_t cs[JU], hs[JU];
+                bool live[JU];
+                uint64_t bits[JU][4];
+#pragma unroll
+                for (int u = 0; u < JU; ++u) {
+                    const uint32_t it = it0 + u;
+                    live[u] = it < items;
+                    const uint32_t b = live[u] ? it / nh : 0;
+                    cs[u] = cand[b];
+                    hs[u] = it - b * nh;
+                }
+                join_blocks<JU>(S, T, idx, m, cs, hs, live, bits);
+#pragma unroll
+                for (int u = 0; u < JU; ++u)
+                    if (lane < 4 && live[u]) rows[4 * (it0 + u) + lane] = pick4(bits[u], lane);
+            }
+        }
+        __syncthreads();
+        if (tid < 64) {
+            // rows do not depend on the state of the grouping: the next candidate's words are read while this one is resolved
+            uint64_t r0 = lane < aw ? rows[lane] : 0, r1 = lane + 64 < aw ? rows[lane + 64] : 0;
+            for (uint32_t b = 0; b < n; ++b) {
+                const uint64_t c0 = r0, c1 = r1;
+                if (b + 1 < n) {
+                    r0 = lane < aw ? rows[(uint64_t)(b + 1) * aw + lane] : 0;
+                    r1 = lane + 64 < aw ? rows[(uint64_t)(b + 1) * aw + lane + 64] : 0;
+                }
+                const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)mycand, (int)b);
+                const uint32_t cw = bit_word(c), cl = bit_lane(c), hl = cw & 63;
+                const uint64_t holder = readlane_u64(cw < 64 ? u0 : u1, hl);
+                if (!((holder >> cl) & 1)) continue;  // absorbed by an earlier seed of this block (uniform)
+                uint64_t n0 = c0 & u0, n1 = c1 & u1;
+                if (lane == hl) { if (cw < 64) n0 |= 1ull << cl; else n1 |= 1ull << cl; }  // the seed itself
+                u0 &= ~n0; u1 &= ~n1;
+                const uint32_t cnt = (uint32_t)__popcll(n0) + (uint32_t)__popcll(n1);
+                if (cnt) atomicAdd(&gsz[G], cnt);
+                while (n0) { grp[bit_pos(lane, (uint32_t)__ffsll((unsigned long long)n0) - 1)] = G; n0 &= n0 - 1; }
+                while (n1) { grp[bit_pos(lane + 64, (uint32_t)__ffsll((unsigned long long)n1) - 1)] = G; n1 &= n1 - 1; }
+                if (lane == 0 && rep) rep[G] = c;
+                ++G;
+            }
+            if (lane == 0) sh_G = G;
+        }
+        __syncthreads();
+        G = __builtin_amdgcn_readfirstlane(sh_G);
+    }
+    return G;
+}
+
 __device__ inline uint32_t greedy_groups(const SimView &S, const uint32_t *__restrict__ idx, uint32_t m, double thr,
                                          const uint32_t *__restrict__ order, uint32_t *grp, uint32_t *gsz, uint32_t *rep,
                                          uint32_t *scratch) {
+    // seeds in position order: the blocked form above (same groups, no barrier and round trip per group); the loop below
+    // serves a handed-in seed order, where a seed's group may reach below it
+    if (!order && m <= 8192) return greedy_groups_bits<false>(nullptr, S, idx, thr, m, grp, gsz, rep, reinterpret_cast<uint64_t *>(scratch));
     const bool by_cutoff = S.gram && S.kind == IMPOP_IDENTITY_MATCH;
     const int64_t hstar = by_cutoff ? match_cutoff(S, thr) : 0;
     __shared__ uint32_t chunk_cnt[ST];
@@ -147,13 +454,8 @@ __device__ inline uint32_t greedy_groups(const SimView &S, const uint32_t *__res
 // after the grouping and leaves rep / group size / G in `split` (per problem: 2 n_el + 4 dwords, then n_el doubles of
 // row sums); pica2_rows_kernel (grid: problems x row chunks) fills the row sums; pica2_finish_kernel adds them in row
 // order and writes the record.  Small problems do everything in pica2_kernel, as before.
-struct Pica2Split {
-    uint32_t *tab;     // problem p: rep[n_el] | gsz[n_el] | G | have | npairs lo | npairs hi
-    double *rowsum;    // problem p: n_el doubles
-};
-__device__ inline uint32_t *split_tab(const Pica2Split &sp, uint64_t p, uint32_t n_el) { return sp.tab + p * (2ull * n_el + 4); }
 
-__global__ __launch_bounds__(ST) void pica2_kernel(SimBatch batch, const uint32_t *__restrict__ idx, uint32_t n_el,
+__global__ __launch_bounds__(ST, 5) void pica2_kernel(SimBatch batch, const uint32_t *__restrict__ idx, uint32_t n_el,
                                                    const uint32_t *__restrict__ order, double threshold,
                                                    const uint64_t *__restrict__ seq_len, Pica2Out *__restrict__ out,
                                                    uint32_t *__restrict__ group_of, Pica2Split split) {
@@ -179,13 +481,15 @@ __global__ __launch_bounds__(ST) void pica2_kernel(SimBatch batch, const uint32_
     // front (the grouping itself makes up to n_el^2 / 2 evaluations), small ones only once they turn out to have many
     // groups (with a handful of groups filling it costs more than it saves)
     __shared__ double sim_tbl[SIM_TBL_N];
-    const bool memo_first = n_el >= 1024;
+    const bool memo_first = n_el >= 1024 && !split.adj;
     if (memo_first) {
         sim_table_fill(S, sim_tbl, ST);
         __syncthreads();
     }
     // Step 1 (pica2.py:94-112)
-    const uint32_t G = greedy_groups(S, idx, n_el, threshold, order, grp, gsz, rep, reinterpret_cast<uint32_t *>(rowsum));
+    const uint32_t G = split.adj ? greedy_groups_bits<true>(split.adj + prob * (uint64_t)n_el * bit_words(n_el), S, idx, threshold, n_el,
+                                                            grp, gsz, rep, reinterpret_cast<uint64_t *>(rowsum))
+                                 : greedy_groups(S, idx, n_el, threshold, order, grp, gsz, rep, reinterpret_cast<uint32_t *>(rowsum));
     if (!memo_first && G >= 48) {  // many groups: the G(G-1)/2 representative pairs then cost a look-up each
         sim_table_fill(S, sim_tbl, ST);
         __syncthreads();
@@ -543,7 +847,7 @@ __device__ inline double hud_first_found(const SimView &S, const uint32_t *ia, c
 }
 // order_a / order_b (nullable): seed orders inside A / B as positions into ia / ib (see greedy_groups)
 // dynamic LDS: rowsum[max(ma,mb)] f64 (grouping scratch first) | grpA[ma] | szA[ma] | repA[ma] | grpB[mb] | szB[mb] | repB[mb]
-__global__ __launch_bounds__(ST) void hud_grouped_kernel(SimBatch batch, const uint32_t *__restrict__ ia, uint32_t ma,
+__global__ __launch_bounds__(ST, 5) void hud_grouped_kernel(SimBatch batch, const uint32_t *__restrict__ ia, uint32_t ma,
                                                          const uint32_t *__restrict__ ib, uint32_t mb,
                                                          const uint32_t *__restrict__ order_a,
                                                          const uint32_t *__restrict__ order_b, double threshold,
@@ -725,14 +1029,24 @@ int launch_pica2(impop_ctx *ctx, const SimBatch &b, uint64_t n_problems, const u
         chunks = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(want / n_problems, 1), n_el / 16);
         if (chunks > 1024) chunks = 1024;
     }
-    Pica2Split split{nullptr, nullptr};
+    Pica2Split split{nullptr, nullptr, nullptr};
     if (chunks > 1) {
         const size_t tab_bytes = ((size_t)n_problems * (2ull * n_el + 4) * 4 + 255) / 256 * 256;
+        const size_t sum_bytes = ((size_t)n_problems * n_el * 8 + 255) / 256 * 256;
+        // seeds in position order (no set order handed in): the join tests of Step 1 go to pica2_adj_kernel, one bit each
+        const size_t adj_bytes = (size_t)n_problems * n_el * bit_words(n_el) * 8;
+        const bool bits = !d_order && n_el <= 8192 && adj_bytes <= ((size_t)2 << 30);
         void *aux = nullptr;
-        const int arc = ctx_aux(ctx, 1, tab_bytes + (size_t)n_problems * n_el * 8, &aux);
+        const int arc = ctx_aux(ctx, 1, tab_bytes + sum_bytes + (bits ? adj_bytes : 0), &aux);
         if (arc) return arc;
         split.tab = reinterpret_cast<uint32_t *>(aux);
         split.rowsum = reinterpret_cast<double *>((char *)aux + tab_bytes);
+        if (bits) {
+            split.adj = reinterpret_cast<uint64_t *>((char *)aux + tab_bytes + sum_bytes);
+            hipLaunchKernelGGL(pica2_adj_kernel, dim3((uint32_t)n_problems, chunks), dim3(ST), b.gram ? (size_t)b.n * 4 : 0, ctx->stream,
+                               b, d_idx, n_el, threshold, split);
+            HIP_TRY(hipGetLastError());
+        }
     }
     if (lds > 48 * 1024)
         HIP_TRY(hipFuncSetAttribute((const void *)pica2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

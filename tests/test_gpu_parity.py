@@ -1245,4 +1245,41 @@ def test_large_problems_split_epilogues(ctx, oracle):
         for k, key in enumerate(("fst", "pi_a", "pi_b", "pi_xy", "dxy", "da")):
             assert rel_close(float(out[k]), want[key], REL, 1e-12 if key in ("fst", "da") else 1e-300), key
         assert (cnt == wcnt).all()
+    # seeds in name order (no seed order handed in): Step 1 runs on the bit matrix pica2_adj_kernel leaves — here on a dense
+    # table with missing pairs (never joins), group by group against the oracle
+    for thr, rd in ((0.9992, 4), (0.99, None), (1.0, None)):
+        pi, ps, grp, G = ctx.pi_from_identity(sim, thr, rd, 777)
+        opi, ops, ogrp, oG = oracle.pica2(sim, thr, 777, rd)
+        assert G == oG and (grp == ogrp).all(), (thr, rd, G, oG)
+        assert rel_close(pi, opi, REL, 1e-300) and rel_close(ps, ops, REL, 1e-300)
+    # ... and on a population subset of the Gram problem (positions != matrix rows)
+    inP = (rng.random(n) < 0.96).astype(np.uint8)
+    sel = np.nonzero(inP)[0]
+    assert len(sel) >= 1024
+    for thr, rd in ((0.999, 5), (1.0, None)):
+        r = bm.pairwise_scan([(0, W, W)], inP, inA, inB, threshold=thr, round_digits=rd, s_scope=2)[0]
+        simw = oracle.identity(oracle.pairwise_counts(bits, n, 0, W), W, 0)
+        pi, ps, _, G = oracle.pica2(simw[np.ix_(sel, sel)], thr, W, rd)
+        assert int(r["n_groups"]) == G and rel_close(float(r["pi"]), pi, REL, 1e-300), (thr, rd)
+    bm.free()
+
+
+def test_bit_matrix_grouping_beyond_4096_elements(ctx, oracle):
+    """More than 4096 elements: the free set of the bit-matrix grouping spans both register words of a lane, candidate
+    blocks are shorter than 64 and the last adjacency word is partial.  Groups element by element against the oracle
+    (non-transitive joins included: noise on seven founders)."""
+    rng = np.random.default_rng(43)
+    n, W = 4199, 700
+    f = (rng.random((7, W)) < 0.5).astype(np.uint8)
+    m = f[rng.integers(0, 7, size=n)] ^ (rng.random((n, W)) < 0.002).astype(np.uint8)
+    bits = oracle.pack_hap_major(m)
+    sim = oracle.identity(oracle.pairwise_counts(bits, n, 0, W), W, 0)
+    for thr, rd in ((0.995, None), (0.997, 3), (1.0, None)):
+        pi, ps, grp, G = ctx.pi_from_identity(sim, thr, rd, W)
+        opi, ops, ogrp, oG = oracle.pica2(sim, thr, W, rd)
+        assert G == oG and (grp == ogrp).all(), (thr, rd, G, oG)
+        assert rel_close(pi, opi, REL, 1e-300)
+    bm = ctx.upload_dense(m, keep_hap_major=True)
+    r = bm.pairwise_scan([(0, W, W)], None, None, None, threshold=0.995, round_digits=None, s_scope=2)[0]
+    assert int(r["n_groups"]) == oracle.pica2(sim, 0.995, W, None)[3]
     bm.free()

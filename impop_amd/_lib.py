@@ -146,6 +146,7 @@ SIGNATURES = {
     "impop_sim_dense": (C.c_int, [_vp, _f64p]),
     "impop_sim_free": (C.c_int, [_vp]),
     "impop_gfa_parse": (C.c_int, [C.c_char_p, C.c_char_p, C.POINTER(_vp)]),
+    "impop_paths_table_parse": (C.c_int, [C.c_char_p, C.POINTER(_vp)]),
     "impop_gfa_info": (C.c_int, [_vp, _u32p, _u64p, _u64p, _i64p]),
     "impop_gfa_names": (C.c_int, [_vp, C.c_char_p]),
     "impop_gfa_bits": (C.c_int, [_vp, _u64p, C.c_uint64]),

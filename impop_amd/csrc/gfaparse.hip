@@ -13,8 +13,10 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <atomic>
 #include <string>
 #include <string_view>
+#include <thread>
 #include <unordered_map>
 #include <vector>
 
@@ -298,6 +300,149 @@ IMPOP_API int impop_gfa_parse(const char *path, const char *ref_prefix, impop_gf
             G->pos[c] = run;
         }
     }
+    *out = G;
+    return done(IMPOP_OK);
+}
+
+// `odgi paths -H` table (scripts/wip/op-afs.py:112 reads the same shape): a header row, three metadata columns (path.name,
+// path.length, node.count), then one column per node holding 0 / visit counts.  Presence = the field is neither "0" nor
+// empty; one site per node (all lengths 1, no coordinates); rows sorted by name (stable).  Same rules as
+// impop_amd/extract.py:from_paths_table, which the caller falls back to on ANY non-zero status.  Rows are independent:
+// line starts are found first, then the rows are parsed by a few threads straight into their bit rows (a 465 x 10^6
+// table is 0.93 GB of text and 58 MB of bits; the Python reader builds 4.6 x 10^8 Python strings on the way).
+IMPOP_API int impop_paths_table_parse(const char *path, impop_gfa **out) {
+    REQUIRE(path && out, "impop_paths_table_parse: NULL argument");
+    *out = nullptr;
+    const int fd = open(path, O_RDONLY);
+    if (fd < 0) {
+        set_error("impop_paths_table_parse: cannot open %s", path);
+        return IMPOP_E_INVALID;
+    }
+    struct stat st;
+    if (fstat(fd, &st) != 0 || !S_ISREG(st.st_mode)) {
+        close(fd);
+        set_error("impop_paths_table_parse: not a regular file: %s", path);
+        return IMPOP_E_UNSUPPORTED;
+    }
+    const size_t size = (size_t)st.st_size;
+    // MAP_POPULATE: the rows are parsed by several threads, and first-touch page faults of one address space serialise
+    const char *data = size ? (const char *)mmap(nullptr, size, PROT_READ, MAP_PRIVATE | MAP_POPULATE, fd, 0) : "";
+    close(fd);
+    if (size && data == MAP_FAILED) {
+        set_error("impop_paths_table_parse: mmap failed for %s", path);
+        return IMPOP_E_UNSUPPORTED;
+    }
+    auto done = [&](int code) {
+        if (size) munmap((void *)data, size);
+        return code;
+    };
+    // Python reads in text mode: "\r\n" and a lone "\r" end a line there.  Leave such files to it.
+    if (size && memchr(data, '\r', size)) {
+        set_error("impop_paths_table_parse: carriage returns in %s (left to the Python reader)", path);
+        return done(IMPOP_E_UNSUPPORTED);
+    }
+    // header: n_node = fields - 3
+    const char *end = data + size;
+    const char *nl = size ? (const char *)memchr(data, '\n', size) : nullptr;
+    const char *hdr_end = nl ? nl : end;
+    uint64_t hdr_fields = 1;
+    for (const char *q = data; q < hdr_end; ++q) hdr_fields += *q == '\t';
+    if (hdr_fields < 4) {
+        set_error("impop_paths_table_parse: %s: expected >= 4 tab-separated columns", path);
+        return done(IMPOP_E_INVALID);
+    }
+    const uint64_t n_node = hdr_fields - 3;
+    // line starts of the non-empty data rows
+    std::vector<std::pair<const char *, const char *>> lines;
+    for (const char *q = nl ? nl + 1 : end; q < end;) {
+        const char *e = (const char *)memchr(q, '\n', (size_t)(end - q));
+        if (!e) e = end;
+        if (e > q) lines.emplace_back(q, e);
+        q = e + 1;
+    }
+    const size_t n = lines.size();
+    auto *G = new impop_gfa();
+    G->words = std::max<uint64_t>((n_node + 63) / 64, 1);
+    std::vector<std::string> names(n);
+    std::vector<uint64_t> bits(n * G->words, 0);
+    std::atomic<size_t> next{0};
+    std::atomic<int> bad{0};
+    auto work = [&]() {
+        for (;;) {
+            const size_t r = next.fetch_add(1);
+            if (r >= n || bad.load(std::memory_order_relaxed)) return;
+            const char *q = lines[r].first, *e = lines[r].second;
+            // three metadata fields
+            const char *f0 = q;
+            int meta = 0;
+            const char *name_end = nullptr;
+            while (q < e && meta < 3) {
+                if (*q == '\t') {
+                    if (meta == 0) name_end = q;
+                    ++meta;
+                }
+                ++q;
+            }
+            if (meta < 3) { bad = 1; return; }
+            names[r].assign(f0, (size_t)(name_end - f0));
+            uint64_t *row = bits.data() + r * G->words;
+            uint64_t col = 0;
+            // node fields.  The common field is one character ("0" / "1"): recognised by the tab (or line end) right
+            // behind it, its presence added without a branch on the DATA (0 / 1 columns are coin flips to a branch
+            // predictor: 8 ns per field with one, 1.5 ns without); longer fields are present, empty ones absent
+            uint64_t word = 0;
+            while (true) {
+                if (col >= n_node) { bad = 1; return; }
+                uint64_t present;
+                if (q < e && *q != '\t' && (q + 1 == e || q[1] == '\t')) {
+                    present = *q != '0';
+                    q += 1;
+                } else {
+                    const char *t = q;
+                    while (t < e && *t != '\t') ++t;
+                    present = t != q;  // length >= 2 (a one-character field went the other way), or empty
+                    q = t;
+                }
+                word |= present << (col & 63);
+                ++col;
+                if ((col & 63) == 0) { row[(col >> 6) - 1] = word; word = 0; }
+                if (q >= e) break;
+                ++q;  // the tab
+                if (q == e) {  // a trailing tab: one more, empty, field
+                    if (col >= n_node) { bad = 1; return; }
+                    ++col;
+                    if ((col & 63) == 0) { row[(col >> 6) - 1] = word; word = 0; }
+                    break;
+                }
+            }
+            if (col & 63) row[col >> 6] = word;
+            if (col != n_node) { bad = 1; return; }
+        }
+    };
+    {
+        unsigned hw = std::thread::hardware_concurrency();
+        const unsigned nt = (unsigned)std::min<size_t>(std::max<size_t>(n, 1), std::min<unsigned>(hw ? hw : 4, 16));
+        std::vector<std::thread> th;
+        for (unsigned k = 1; k < nt; ++k) th.emplace_back(work);
+        work();
+        for (auto &t : th) t.join();
+    }
+    if (bad) {
+        delete G;
+        set_error("impop_paths_table_parse: %s: a row's field count differs from the header's", path);
+        return done(IMPOP_E_INVALID);
+    }
+    // engine convention: lexicographic name order, stable (sorted(range(n), key = name))
+    std::vector<size_t> order(n);
+    for (size_t i = 0; i < n; ++i) order[i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return names[a] < names[b]; });
+    G->names.resize(n);
+    G->bits.assign(n * G->words, 0);
+    for (size_t i = 0; i < n; ++i) {
+        G->names[i] = std::move(names[order[i]]);
+        memcpy(G->bits.data() + i * G->words, bits.data() + order[i] * G->words, G->words * 8);
+    }
+    G->seg_len.assign(n_node, 1u);
     *out = G;
     return done(IMPOP_OK);
 }

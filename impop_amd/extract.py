@@ -16,10 +16,59 @@ import numpy as np
 from .matrixio import MatrixFile, from_dense
 
 
-def from_paths_table(path: str) -> MatrixFile:
+def _handle_to_matrix(lib, h, with_lengths: bool, ref_prefix: Optional[str]) -> MatrixFile:
+    """names / bits / (lengths, positions) out of a native parser handle (impop_gfa_*)."""
+    import ctypes as C
+
+    from . import _lib
+    n, n_seg, nb, ref_row = C.c_uint32(), C.c_uint64(), C.c_uint64(), C.c_int64()
+    _lib.check(lib.impop_gfa_info(h, C.byref(n), C.byref(n_seg), C.byref(nb), C.byref(ref_row)))
+    buf = C.create_string_buffer(max(nb.value, 1))
+    _lib.check(lib.impop_gfa_names(h, buf))
+    names = [x.decode("utf-8", "surrogateescape") for x in buf.raw[: nb.value].split(b"\0")[: n.value]]
+    words = max((n_seg.value + 63) // 64, 1)
+    bits = np.zeros((n.value, words), dtype=np.uint64)
+    _lib.check(lib.impop_gfa_bits(h, bits.ctypes.data_as(C.POINTER(C.c_uint64)), words))
+    mf = MatrixFile(bits=bits, n_site=int(n_seg.value), names=names)
+    if with_lengths:
+        lens = np.zeros(n_seg.value, dtype=np.uint32)
+        _lib.check(lib.impop_gfa_lengths(h, lens.ctypes.data_as(C.POINTER(C.c_uint32))))
+        mf.site_weight = lens
+    if ref_prefix is not None:
+        pos = np.zeros(n_seg.value, dtype=np.int64)
+        _lib.check(lib.impop_gfa_positions(h, pos.ctypes.data_as(C.POINTER(C.c_int64))))
+        mf.site_pos = pos
+        mf.contig = ref_prefix or ""
+    return mf
+
+
+def _from_paths_table_native(path: str) -> Optional[MatrixFile]:
+    """The table through the native parser in libimpop_hip.so (impop_paths_table_parse: rows parsed by several threads
+    straight into bit rows).  None on ANY non-zero status: the Python code below then handles the file and raises
+    whatever it raises."""
+    import ctypes as C
+    import os
+
+    from . import _lib
+    lib = _lib.load()
+    h = C.c_void_p()
+    if lib.impop_paths_table_parse(os.fsencode(path), C.byref(h)) != 0:
+        return None
+    try:
+        return _handle_to_matrix(lib, h, False, None)
+    finally:
+        lib.impop_gfa_free(h)
+
+
+def from_paths_table(path: str, native: bool = True) -> MatrixFile:
     """`odgi paths -H`-style table: a header row, three metadata columns (path.name, path.length,
     node.count), then one column per node holding 0 / visit counts (op-afs.py:112 reads it the
-    same way).  Presence = count != 0; one site per node."""
+    same way).  Presence = count != 0; one site per node.  native=True reads through
+    impop_paths_table_parse (same matrix, two orders of magnitude faster); any file it declines comes here."""
+    if native:
+        mf = _from_paths_table_native(path)
+        if mf is not None:
+            return mf
     names: List[str] = []
     rows: List[np.ndarray] = []
     with open(path) as f:
@@ -57,24 +106,7 @@ def _from_gfa_native(path: str, ref_prefix: Optional[str]) -> Optional[MatrixFil
     if lib.impop_gfa_parse(os.fsencode(path), None if ref_prefix is None else ref_prefix.encode(), C.byref(h)) != 0:
         return None
     try:
-        n, n_seg, nb, ref_row = C.c_uint32(), C.c_uint64(), C.c_uint64(), C.c_int64()
-        _lib.check(lib.impop_gfa_info(h, C.byref(n), C.byref(n_seg), C.byref(nb), C.byref(ref_row)))
-        buf = C.create_string_buffer(max(nb.value, 1))
-        _lib.check(lib.impop_gfa_names(h, buf))
-        names = [x.decode("utf-8", "surrogateescape") for x in buf.raw[: nb.value].split(b"\0")[: n.value]]
-        words = max((n_seg.value + 63) // 64, 1)
-        bits = np.zeros((n.value, words), dtype=np.uint64)
-        _lib.check(lib.impop_gfa_bits(h, bits.ctypes.data_as(C.POINTER(C.c_uint64)), words))
-        lens = np.zeros(n_seg.value, dtype=np.uint32)
-        _lib.check(lib.impop_gfa_lengths(h, lens.ctypes.data_as(C.POINTER(C.c_uint32))))
-        mf = MatrixFile(bits=bits, n_site=int(n_seg.value), names=names)
-        mf.site_weight = lens
-        if ref_prefix is not None:
-            pos = np.zeros(n_seg.value, dtype=np.int64)
-            _lib.check(lib.impop_gfa_positions(h, pos.ctypes.data_as(C.POINTER(C.c_int64))))
-            mf.site_pos = pos
-            mf.contig = ref_prefix or ""
-        return mf
+        return _handle_to_matrix(lib, h, True, ref_prefix)
     finally:
         lib.impop_gfa_free(h)
 

@@ -409,6 +409,11 @@ int impop_gfa_bits(const impop_gfa *g, uint64_t *bits_hap_major, uint64_t row_st
 int impop_gfa_lengths(const impop_gfa *g, uint32_t *lengths);            /* per column */
 int impop_gfa_positions(const impop_gfa *g, int64_t *positions);         /* per column; needs ref_prefix */
 int impop_gfa_free(impop_gfa *g);
+/* `odgi paths -H` table (header row; path.name, path.length, node.count; then one 0 / visit-count column per node — the
+ * shape scripts/wip/op-afs.py:112 reads) -> the same handle: rows sorted by name, one column per node (all lengths 1,
+ * no positions).  Rows are parsed by several host threads.  Same rules as impop_amd/extract.py:from_paths_table, which
+ * the caller falls back to on ANY non-zero status. */
+int impop_paths_table_parse(const char *path, impop_gfa **out);
 
 /* CPython round(x, ndigits) (pica2.py:83, h-fst.py:150) evaluated on the GPU,
  * exposed so that the device implementation can be fuzzed against CPython. */

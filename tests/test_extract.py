@@ -1,6 +1,7 @@
 """CPU: presence-matrix extractors and the matrix container (SURVEY §8f-2/3 host side)."""
 
 import numpy as np
+import pytest
 
 import impop_amd
 from impop_amd import extract, matrixio
@@ -124,3 +125,47 @@ def test_native_gfa_parser_equals_python_extractor(tmp_path):
     assert extract._from_gfa_native(str(tmp_path / "t2.gfa"), "NOPE#") is None
     with pytest.raises(ValueError):
         extract.from_gfa(str(tmp_path / "t2.gfa"), ref_prefix="NOPE#", expand_bp=False)
+
+
+def test_native_paths_table_parser_equals_python_reader(tmp_path):
+    """impop_paths_table_parse (host C++ in libimpop_hip.so, rows parsed by several threads) against
+    extract.from_paths_table(native=False), the definition: names, order, packed bits — with visit counts > 1, empty
+    fields, duplicate names (stable order), no trailing newline, blank lines; files the native parser declines (ragged
+    rows, CRLF, too few columns) fall back to the Python reader and its error texts."""
+    rng = np.random.default_rng(9)
+    for trial, (n, W) in enumerate([(1, 1), (7, 63), (23, 64), (40, 1000), (3, 129)]):
+        p = tmp_path / f"t{trial}.tsv"
+        names = [f"s{int(rng.integers(0, 12))}#{int(rng.integers(1, 3))}#c" for _ in range(n)]
+        rows = ["path.name\tpath.length\tnode.count\t" + "\t".join(f"node.{k + 1}" for k in range(W))]
+        for nm in names:
+            fields = [("" if rng.random() < 0.05 else str(int(v))) for v in rng.choice([0, 0, 0, 1, 1, 2, 10, 100], size=W)]
+            rows.append(f"{nm}\t{int(rng.integers(1, 999))}\t{W}\t" + "\t".join(fields))
+            if rng.random() < 0.2:
+                rows.append("")   # blank line: skipped
+        text = "\n".join(rows) + ("\n" if trial % 2 else "")
+        p.write_text(text)
+        want = extract.from_paths_table(str(p), native=False)
+        got = extract._from_paths_table_native(str(p))
+        assert got is not None
+        assert got.names == want.names and got.n_site == want.n_site == W
+        assert got.bits.shape == want.bits.shape and (got.bits == want.bits).all()
+        assert got.site_weight is None and got.site_pos is None
+        assert (extract.from_paths_table(str(p)).bits == want.bits).all()
+    ragged = tmp_path / "ragged.tsv"
+    ragged.write_text("path.name\tpath.length\tnode.count\tn1\tn2\na\t1\t2\t1\t0\nb\t1\t2\t1\n")
+    assert extract._from_paths_table_native(str(ragged)) is None
+    with pytest.raises(ValueError, match="fields, expected 5"):
+        extract.from_paths_table(str(ragged))
+    long_row = tmp_path / "long.tsv"
+    long_row.write_text("path.name\tpath.length\tnode.count\tn1\na\t1\t1\t1\t0\n")
+    assert extract._from_paths_table_native(str(long_row)) is None
+    crlf = tmp_path / "crlf.tsv"
+    crlf.write_bytes(b"path.name\tpath.length\tnode.count\tn1\tn2\r\na\t1\t2\t1\t0\r\n")
+    assert extract._from_paths_table_native(str(crlf)) is None
+    assert impop_amd.unpack_hap_major(extract.from_paths_table(str(crlf)).bits, 2).tolist() == [[1, 0]]
+    few = tmp_path / "few.tsv"
+    few.write_text("a\tb\tc\n")
+    assert extract._from_paths_table_native(str(few)) is None
+    with pytest.raises(ValueError, match="expected >= 4"):
+        extract.from_paths_table(str(few))
+    assert extract._from_paths_table_native(str(tmp_path / "missing.tsv")) is None

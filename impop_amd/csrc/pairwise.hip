@@ -252,6 +252,11 @@ __device__ __forceinline__ void gram_task(const uint32_t *__restrict__ rb, uint6
 // (4 x 9 MFMAs = 1152 cycles) before its next use.
 typedef int i32x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+struct GramPlanes {          // bit planes of the site weights (weight_planes_kernel), nullptr = unweighted
+    const uint32_t *planes;  // plane k at planes + k * stride, one bit per site (dword d = sites 32 d ..)
+    uint64_t stride;         // dwords per plane
+    uint32_t bits;           // planes with any set bit
+};
 constexpr uint32_t FP4_MAX_SLICE_PAIRS = (1u << 24) / 128;  // fp32 accumulators stay exact integers
 
 __device__ __forceinline__ i32x4 fp4_planes(uint32_t x) {
@@ -271,10 +276,17 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 template <bool DIAG>
 __device__ __forceinline__ void gram_task_fp4(const uint32_t *__restrict__ rb, uint64_t nb_row, uint32_t ti, uint32_t tj,
                                               const GramWindow w, uint32_t ks, uint32_t ksplit, int32_t *__restrict__ o,
-                                              uint32_t ld) {
+                                              uint32_t ld, uint32_t shift, bool add, const GramPlanes wp) {
     constexpr int NB = DIAG ? 0 : 3;
     constexpr int NM = DIAG ? 6 : 9;  // MFMAs per phase
     const uint32_t lane = threadIdx.x & 63, r32 = lane & 31, hi_half = lane >> 5;
+    // Weighted sites in ONE task (wp.planes != nullptr): I = sum_k 2^k Gram(M & W_k) by Horner over the used bit planes of
+    // the weights, highest first — the K loop below runs once per plane with the plane's words ANDed into the A-side mask,
+    // the 144 accumulators are doubled in between (exact: powers of two, totals below 2^24) and written ONCE.  One launch
+    // per plane instead (operand masked by a separate kernel, (count << k) added into the output) re-wrote the 480^2
+    // counts of every window twelve times: 0.9 ms per plane and 2048 node-level windows, most of it output traffic.
+    uint32_t plane_left = wp.planes ? wp.bits : 1u;
+    uint32_t kcur = 31u - (uint32_t)__builtin_clz(plane_left);
     f32x16 acc[3][3];
 #pragma unroll
     for (int a = 0; a < 3; ++a)
@@ -302,6 +314,15 @@ __device__ __forceinline__ void gram_task_fp4(const uint32_t *__restrict__ rb, u
         auto lane_mask = [&](uint32_t u, int d) -> uint32_t {
             const uint32_t d0 = 4 * u + d;  // dword index of lane half 0 (cell 2u); lane half 1 is one cell (2 dwords) on
             return (hsel & mask_of(d0 + 2, u < uend)) | (~hsel & mask_of(d0, u < uend));
+        };
+        // the current plane's words for the same two dwords (uniform addresses: scalar loads); past the plane's end the
+        // window mask is zero anyway, so the index is only clamped
+        const uint32_t *P = nullptr;
+        const uint64_t p_lim = wp.planes ? wp.stride - 1 - 2 * cell0 : 0;  // 2 * cell0 < stride: the window starts inside the matrix
+        auto plane_mask = [&](uint32_t u, int d) -> uint32_t {
+            const uint64_t d0 = 4ull * u + d;
+            const uint32_t w0 = P[d0 < p_lim ? d0 : p_lim], w1 = P[d0 + 2 < p_lim ? d0 + 2 : p_lim];
+            return (hsel & w1) | (~hsel & w0);
         };
         // Buffer loads: one descriptor per 32-row group, based at the slice's first pair (SGPRs only), the
         // constant per-lane byte offset in voffset and the pair index in soffset: no address VALU at all.
@@ -393,10 +414,16 @@ __device__ __forceinline__ void gram_task_fp4(const uint32_t *__restrict__ rb, u
             mA = lane_mask((U), 1);                                                 \
             mB = lane_mask((U) + 1, 0);                                             \
         }                                                                           \
+        if (P) {                                                                    \
+            mA &= plane_mask((U), 1);                                               \
+            mB &= plane_mask((U) + 1, 0);                                           \
+        }                                                                           \
         const uint32_t soff = pair_soff((U) + 3);                                   \
         FP4_PHASE(F, G, CUR, 1, mA, CUR, soff, false);                              \
         FP4_PHASE(G, F, NXT, 0, mB, CUR, soff, true);                               \
     } while (0)
+        do {  // once, or once per used weight plane (a plain bottom-tested loop: more exits make the compiler shuffle the accumulators)
+        if (wp.planes) P = wp.planes + (uint64_t)kcur * wp.stride + 2 * cell0;
         if (ubeg < uend) {
             Cell C0, C1, C2;
             Frag F, G;
@@ -407,7 +434,7 @@ __device__ __forceinline__ void gram_task_fp4(const uint32_t *__restrict__ rb, u
                 load_one(C2, i, pair_soff(ubeg + 2));
             }
             {
-                const uint32_t m0 = lane_mask(ubeg, 0);
+                const uint32_t m0 = lane_mask(ubeg, 0) & (P ? plane_mask(ubeg, 0) : 0xFFFFFFFFu);
                 uint32_t xm;
 #pragma unroll
                 for (int g = 0; g < 3; ++g) {
@@ -429,10 +456,24 @@ __device__ __forceinline__ void gram_task_fp4(const uint32_t *__restrict__ rb, u
                 FP4_PAIR(C2, C0, u + 2);
             }
         }
+        asm volatile("s_nop 15\n\ts_nop 15");  // last MFMA results -> the VALU conversions / doublings below
+        plane_left &= ~(1u << kcur);
+        const uint32_t knext = plane_left ? 31u - (uint32_t)__builtin_clz(plane_left) : kcur;
+        const float up = (float)(1u << (kcur - knext));  // planes without a set bit in between are skipped; x1 after the last
+        kcur = knext;
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int b = 0; b < 3; ++b) {
+                if (DIAG && b < a) continue;
+                acc[a][b] *= up;
+            }
+        asm volatile("s_nop 7");  // VALU-written accumulators -> the next plane's first MFMA
+        } while (plane_left);
 #undef FP4_PAIR
 #undef FP4_PHASE
-        asm volatile("s_nop 15\n\ts_nop 15");  // last MFMA results -> the VALU conversions below
     }
+    if (wp.planes) shift += kcur;  // Horner stopped at the lowest used plane (an empty window never started: its zeros shift to zero)
 #pragma unroll
     for (int a = 0; a < 3; ++a)
 #pragma unroll
@@ -442,8 +483,9 @@ __device__ __forceinline__ void gram_task_fp4(const uint32_t *__restrict__ rb, u
             for (int e = 0; e < 16; ++e) {
                 const uint32_t row = ti * GT + 32 * a + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
                 const uint32_t col = tj * GT + 32 * b + r32;
-                const int32_t v = (int32_t)acc[a][b][e];
-                if (ksplit == 1) o[(uint64_t)row * ld + col] = v;
+                // weighted matrices: this launch is bit plane `shift` of the site weights, added into the other planes' sum
+                const int32_t v = (int32_t)((uint32_t)(int32_t)acc[a][b][e] << shift);
+                if (ksplit == 1 && !add) o[(uint64_t)row * ld + col] = v;
                 else atomicAdd(&o[(uint64_t)row * ld + col], v);
             }
         }
@@ -453,7 +495,8 @@ __device__ __forceinline__ void gram_task_fp4(const uint32_t *__restrict__ rb, u
 __global__ __launch_bounds__(256, 2) void gram_fp4_kernel(const uint32_t *__restrict__ rb, uint64_t nb_row, uint32_t n_tiles,
                                                           uint32_t tasks_per_win, uint32_t n_win, uint32_t ksplit,
                                                           const GramWindow *__restrict__ wins, int32_t *__restrict__ out,
-                                                          uint32_t ld, uint64_t out_stride, uint32_t *__restrict__ queue_heads) {
+                                                          uint32_t ld, uint64_t out_stride, uint32_t *__restrict__ queue_heads,
+                                                          uint32_t shift, bool add, GramPlanes wp) {
     const uint32_t slots = tasks_per_win * ksplit;
     const bool by_window = n_win >= 8;
     const uint64_t total = (uint64_t)n_win * slots;
@@ -473,8 +516,8 @@ __global__ __launch_bounds__(256, 2) void gram_fp4_kernel(const uint32_t *__rest
             while (rem >= n_tiles - ti) { rem -= n_tiles - ti; ++ti; }
             const uint32_t tj = ti + rem;
             int32_t *o = out + (uint64_t)win * out_stride;
-            if (ti == tj) gram_task_fp4<true>(rb, nb_row, ti, tj, wins[win], ks, ksplit, o, ld);
-            else gram_task_fp4<false>(rb, nb_row, ti, tj, wins[win], ks, ksplit, o, ld);
+            if (ti == tj) gram_task_fp4<true>(rb, nb_row, ti, tj, wins[win], ks, ksplit, o, ld, shift, add, wp);
+            else gram_task_fp4<false>(rb, nb_row, ti, tj, wins[win], ks, ksplit, o, ld, shift, add, wp);
         }
     }
 }
@@ -581,8 +624,11 @@ static bool gram_use_fp4() {
     return v;
 }
 
+// add_shift < 0: d_out = Gram; >= 0 (FP4 kernel only): d_out += Gram << add_shift (d_out holds the other planes' sum).
+// fused_planes (FP4 kernel only): the weighted Gram matrix of m in one launch (gram_task_fp4), every window's summed
+// weight below 2^24.
 static int launch_gram(impop_ctx *ctx, const impop_matrix *m, const uint32_t *d_rb, const GramWindow *d_wins, uint32_t n_win,
-                       int32_t *d_out, uint64_t max_window_sites) {
+                       int32_t *d_out, uint64_t max_window_sites, int add_shift = -1, bool fused_planes = false) {
     const uint32_t T = m->n_hap_pad / GT;
     const uint32_t tasks_per_win = T * (T + 1) / 2;  // upper-triangular tile pairs
     // two waves per SIMD on every CU = 8 * n_cu resident waves; aim at >= 4 rounds of them so the
@@ -592,7 +638,7 @@ static int launch_gram(impop_ctx *ctx, const impop_matrix *m, const uint32_t *d_
     while ((uint64_t)n_win * tasks_per_win * ksplit < want && ksplit < 64) ksplit *= 2;
     // FP4: fp32 accumulators must stay below 2^24 per K-slice
     while (gram_use_fp4() && (max_window_sites / 128 + 2) / ksplit + 1 > FP4_MAX_SLICE_PAIRS) ksplit *= 2;
-    if (ksplit > 1)
+    if (ksplit > 1 && add_shift < 0)
         HIP_TRY(hipMemsetAsync(d_out, 0, (size_t)n_win * m->n_hap_pad * m->n_hap_pad * sizeof(int32_t), ctx->stream));
     REQUIRE((uint64_t)n_win * tasks_per_win * ksplit < 0xFFFFFFF0ull, "gram: too many tasks for one launch");
     if (!ctx->d_queue) HIP_TRY(hipMalloc((void **)&ctx->d_queue, 8 * sizeof(uint32_t)));
@@ -601,9 +647,12 @@ static int launch_gram(impop_ctx *ctx, const impop_matrix *m, const uint32_t *d_
     const uint32_t n_cu = (uint32_t)(ctx->n_cu > 0 ? ctx->n_cu : 256);
     const uint64_t need_wg = ((uint64_t)n_win * tasks_per_win * ksplit + 3) / 4;
     const uint32_t grid = (uint32_t)std::max<uint64_t>(8, std::min<uint64_t>(2ull * n_cu, need_wg));
+    GramPlanes wp{nullptr, 0, 0};
+    if (fused_planes) wp = GramPlanes{m->d_wplanes, m->wplane_stride, m->wplane_bits};
     if (gram_use_fp4())
         hipLaunchKernelGGL(gram_fp4_kernel, dim3(grid), dim3(256), 0, ctx->stream, d_rb, m->rb_nb, T, tasks_per_win, n_win,
-                           ksplit, d_wins, d_out, m->n_hap_pad, (uint64_t)m->n_hap_pad * m->n_hap_pad, ctx->d_queue);
+                           ksplit, d_wins, d_out, m->n_hap_pad, (uint64_t)m->n_hap_pad * m->n_hap_pad, ctx->d_queue,
+                           add_shift < 0 ? 0u : (uint32_t)add_shift, add_shift >= 0, wp);
     else
         hipLaunchKernelGGL(gram_mfma_kernel, dim3(grid), dim3(256), 0, ctx->stream, d_rb, m->rb_nb, T, tasks_per_win, n_win,
                            ksplit, d_wins, d_out, m->n_hap_pad, (uint64_t)m->n_hap_pad * m->n_hap_pad, ctx->d_queue);
@@ -618,8 +667,10 @@ static int launch_gram(impop_ctx *ctx, const impop_matrix *m, const uint32_t *d_
 // Write w_s = sum_k 2^k w_ks with bit planes w_ks in {0,1}.  Masking the site axis with plane k gives a 0/1
 // matrix M_k = M & W_k whose plain Gram matrix is sum_s w_ks b_is b_js (w_ks^2 = w_ks), so
 //     I = sum_k 2^k Gram(M_k)
-// with the UNCHANGED matrix-core kernel: per plane one elementwise AND of the RB32 operand (only the cells the
-// batch touches), one Gram launch, one shifted integer accumulate.  Exact by construction (every partial Gram is
+// with the same matrix-core kernel: per plane one elementwise AND of the RB32 operand (only the cells the batch
+// touches) and one Gram launch whose epilogue ADDS (count << k) into the sum of the planes before it (integer atomics:
+// a separate shifted-accumulate pass over 4096 x 480^2 counts cost 1.0 ms per plane, twice the Gram launch it followed —
+// tools/bench_weighted.py: 46 -> 19 ms per 4096 node-level windows of 12 planes).  Exact by construction (every partial Gram is
 // an exact integer; the sum is required to stay below 2^31 like the length of an unweighted window); planes
 // without any set bit are skipped, so node lengths below 2^p cost p Gram launches over the NODE-level matrix —
 // against mean-node-length times the MACs for the bp-expanded one.
@@ -697,6 +748,15 @@ static int launch_gram_any(impop_ctx *ctx, const impop_matrix *m, const GramWind
             c_hi = std::max(c_hi, (h_wins[i].site_end + 63) >> 6);
         }
     const uint64_t count = (uint64_t)n_win * m->n_hap_pad * m->n_hap_pad;
+    // every window lighter than 2^24 (fp32-exact sums) and some weight bit set: all planes inside one launch (Horner in
+    // gram_task_fp4); IMPOP_GRAM_PLANES=split keeps the launch-per-plane form for A/B measurements
+    static const bool split_planes = [] { const char *e = getenv("IMPOP_GRAM_PLANES"); return e && e[0] == 's'; }();
+    uint64_t heaviest = 0;
+    for (uint32_t i = 0; i < n_win; ++i)
+        if (h_wins[i].site_end > h_wins[i].site_begin)
+            heaviest = std::max(heaviest, m->wt_prefix[h_wins[i].site_end] - m->wt_prefix[h_wins[i].site_begin]);
+    if (gram_use_fp4() && !split_planes && m->wplane_bits && heaviest < (1ull << 24))
+        return launch_gram(ctx, m, m->d_rb, d_wins, n_win, d_out, max_window_sites, -1, true);
     HIP_TRY(hipMemsetAsync(d_out, 0, count * 4, ctx->stream));
     if (c_lo >= c_hi) return IMPOP_OK;
     c_hi = std::min<uint64_t>(c_hi + 8, m->rb_nb);  // the Gram pipeline prefetches a few cells past a window's end
@@ -708,6 +768,11 @@ static int launch_gram_any(impop_ctx *ctx, const impop_matrix *m, const GramWind
         hipLaunchKernelGGL(rb_mask_kernel, dim3((uint32_t)((threads + 255) / 256)), dim3(256), 0, ctx->stream, m->d_rb, m->d_rb_masked,
                            m->rb_nb, n_group, c_lo, c_hi, m->d_wplanes + (uint64_t)k * m->wplane_stride, m->wplane_stride);
         HIP_TRY(hipGetLastError());
+        if (gram_use_fp4()) {  // the plane's shift and the sum over planes happen in the Gram kernel's own stores
+            rc = launch_gram(ctx, m, m->d_rb_masked, d_wins, n_win, d_out, max_window_sites, (int)k);
+            if (rc) return rc;
+            continue;
+        }
         rc = launch_gram(ctx, m, m->d_rb_masked, d_wins, n_win, d_tmp, max_window_sites);
         if (rc) return rc;
         hipLaunchKernelGGL(gram_accumulate_kernel, dim3((uint32_t)((count + 255) / 256)), dim3(256), 0, ctx->stream, d_out, d_tmp, k, count);

@@ -1131,6 +1131,39 @@ def test_weighted_gram_equals_bp_expanded_matrix(ctx, oracle):
     big.free()
 
 
+def test_weighted_gram_plane_walks(ctx):
+    """The two ways the weight planes are walked: inside one task (Horner on the fp32 accumulators; windows lighter than
+    2^24) — with unused planes between used ones, a single used plane, only high planes — and one launch per plane with
+    (count << k) added by the epilogue (heavier windows).  Both against numpy, on full, unaligned and batched windows."""
+    rng = np.random.default_rng(77)
+    n, K = 70, 700
+    m = (rng.random((n, K)) < rng.random(K)).astype(np.uint8)
+    mi = m.astype(np.int64)
+    bm = ctx.upload_dense(m, keep_hap_major=True)
+    spans = [(0, K), (13, 77), (64, 128), (129, 700), (300, 301)]
+    for name, w in (("gaps", rng.choice([1, 16, 17, 4097, 8192], size=K)),      # planes 0, 4, 12, 13
+                    ("one plane", np.full(K, 64)),
+                    ("high planes", rng.choice([1 << 12, 1 << 13, 3 << 12], size=K)),
+                    ("dense bits", rng.integers(1, 1 << 10, size=K)),
+                    ("heavy", rng.integers(1 << 15, 1 << 19, size=K))):         # 700 x 2^18 > 2^24: launch per plane
+        w = w.astype(np.uint32)
+        bm.set_site_weights(w)
+        for a, b in spans:
+            want = (mi[:, a:b] * w[a:b].astype(np.int64)) @ mi[:, a:b].T
+            assert want.max() < 2 ** 31
+            got = bm.pairwise_counts(a, b).astype(np.int64)
+            assert (got == want).all(), (name, a, b)
+        # a batch of windows (different weights per window, light and — in the heavy case — heavy ones mixed)
+        cum = np.concatenate(([0], np.cumsum(w.astype(np.int64))))
+        wins = [(a, b, int(cum[b] - cum[a])) for a, b in spans]
+        recs = bm.pairwise_scan(wins, None, None, None, kind="dice", threshold=0.9, round_digits=None, s_scope=2)
+        for (a, b, L), r in zip(wins, recs):
+            one = bm.pairwise_scan([(a, b, L)], None, None, None, kind="dice", threshold=0.9, round_digits=None, s_scope=2)[0]
+            assert r.tobytes() == one.tobytes(), (name, a, b)
+            assert int(r["n_sites"]) == L
+    bm.free()
+
+
 def test_config5_full_size_gram_and_scan_properties(ctx):
     """BASELINE config 5 at FULL size — 4096 haplotypes x 10^7 sites (5.12 GB) resident, ONE window — on both paths,
     through properties that need no oracle: the K-split FP4 Gram matrix is symmetric, reproducible byte for byte,

@@ -132,6 +132,7 @@ struct impop_matrix {
     bool compact = false;
     uint64_t n_site_orig = 0;
     std::vector<uint64_t> pos;
+    std::vector<uint64_t> pos_coarse;  // pos[k << POS_COARSE_SHIFT]: a cache-resident first level for pos_lower_bound
     std::vector<uint64_t> wt_prefix;  // weighted: prefix sums of the (ORIGINAL, if compacted) site weights, n + 1 entries
     int device = 0;
     mutable int users = 0;      // live scan plans referencing this matrix (impop_matrix_free refuses while > 0)
@@ -148,6 +149,9 @@ int ensure_tajima_consts(impop_ctx *ctx, int64_t n);  // fills ctx->d_taj for n 
 // ranges (`mapped`), else `mapped` is a plain copy.  span() = the coordinate range windows must lie in.
 inline uint64_t matrix_span(const impop_matrix *m) { return m->compact ? m->n_site_orig : m->g.n_site; }
 void map_windows(const impop_matrix *m, const impop_window *windows, uint64_t n, std::vector<impop_window> &mapped);
+// compacted matrices: index of the first kept site at or right of original coordinate s (= number of kept sites left of s)
+uint64_t pos_lower_bound(const impop_matrix *m, uint64_t s);
+constexpr unsigned POS_COARSE_SHIFT = 12;
 
 // layout.hip
 int launch_hm_to_sb(impop_ctx *ctx, const uint32_t *d_hm, uint64_t hm_stride, const SbGeom &g, uint32_t *d_sb);

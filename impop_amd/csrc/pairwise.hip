@@ -836,8 +836,8 @@ __global__ void gram_add_const_kernel(int32_t *__restrict__ g, uint32_t ld, uint
 // kept-site index range of an original-coordinate range on a compacted matrix (identity otherwise)
 static inline void map_range(const impop_matrix *m, uint64_t s0, uint64_t s1, uint64_t *k0, uint64_t *k1) {
     if (!m->compact) { *k0 = s0; *k1 = s1; return; }
-    *k0 = (uint64_t)(std::lower_bound(m->pos.begin(), m->pos.end(), s0) - m->pos.begin());
-    *k1 = (uint64_t)(std::lower_bound(m->pos.begin(), m->pos.end(), s1) - m->pos.begin());
+    *k0 = pos_lower_bound(m, s0);
+    *k1 = pos_lower_bound(m, s1);
 }
 
 int ensure_segmap(impop_ctx *ctx, const impop_matrix *m) {

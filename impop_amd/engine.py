@@ -87,9 +87,14 @@ def make_windows(windows) -> np.ndarray:
         return np.ascontiguousarray(windows)
     rows = list(windows)
     out = np.zeros(len(rows), dtype=WINDOW_DTYPE)
-    for i, r in enumerate(rows):
-        out[i]["site_begin"], out[i]["site_end"] = int(r[0]), int(r[1])
-        out[i]["seq_len"] = int(r[2]) if len(r) > 2 and r[2] is not None else max(int(r[1]) - int(r[0]), 0)
+    if not rows:
+        return out
+    # column-wise (a BED file's worth of tuples costs a Python loop over fields otherwise: 1.5 us per field)
+    begin = np.fromiter((int(r[0]) for r in rows), dtype=np.uint64, count=len(rows))
+    end = np.fromiter((int(r[1]) for r in rows), dtype=np.uint64, count=len(rows))
+    out["site_begin"], out["site_end"] = begin, end
+    out["seq_len"] = np.fromiter((int(r[2]) if len(r) > 2 and r[2] is not None else max(int(r[1]) - int(r[0]), 0) for r in rows),
+                                 dtype=np.uint64, count=len(rows))
     return out
 
 

@@ -660,6 +660,14 @@ static int launch_gram(impop_ctx *ctx, const impop_matrix *m, const uint32_t *d_
     return IMPOP_OK;
 }
 
+// every window lighter than 2^24 (fp32-exact sums): all weight planes inside one launch (Horner in gram_task_fp4);
+// IMPOP_GRAM_PLANES=split keeps the launch-per-plane form for A/B measurements
+constexpr uint64_t GRAM_FUSED_WEIGHT_LIMIT = 1ull << 24;
+static bool gram_planes_in_task() {
+    static const bool split_planes = [] { const char *e = getenv("IMPOP_GRAM_PLANES"); return e && e[0] == 's'; }();
+    return gram_use_fp4() && !split_planes;
+}
+
 // ---- weighted sites on the all-pairs path ------------------------------------------------------------------
 // Column s stands for w_s base pairs (one column per graph node, impop_matrix_set_site_weights): what `impg
 // similarity` hands the reference is a bp-weighted node-sharing identity (run_pica2_impg.sh:162-175), i.e.
@@ -748,15 +756,13 @@ static int launch_gram_any(impop_ctx *ctx, const impop_matrix *m, const GramWind
             c_hi = std::max(c_hi, (h_wins[i].site_end + 63) >> 6);
         }
     const uint64_t count = (uint64_t)n_win * m->n_hap_pad * m->n_hap_pad;
-    // every window lighter than 2^24 (fp32-exact sums) and some weight bit set: all planes inside one launch (Horner in
-    // gram_task_fp4); IMPOP_GRAM_PLANES=split keeps the launch-per-plane form for A/B measurements
-    static const bool split_planes = [] { const char *e = getenv("IMPOP_GRAM_PLANES"); return e && e[0] == 's'; }();
     uint64_t heaviest = 0;
     for (uint32_t i = 0; i < n_win; ++i)
         if (h_wins[i].site_end > h_wins[i].site_begin)
             heaviest = std::max(heaviest, m->wt_prefix[h_wins[i].site_end] - m->wt_prefix[h_wins[i].site_begin]);
-    if (gram_use_fp4() && !split_planes && m->wplane_bits && heaviest < (1ull << 24))
+    if (gram_planes_in_task() && m->wplane_bits && heaviest < GRAM_FUSED_WEIGHT_LIMIT)
         return launch_gram(ctx, m, m->d_rb, d_wins, n_win, d_out, max_window_sites, -1, true);
+    REQUIRE(d_tmp || !m->wplane_bits, "weighted Gram: no buffer for the plane partials");
     HIP_TRY(hipMemsetAsync(d_out, 0, count * 4, ctx->stream));
     if (c_lo >= c_hi) return IMPOP_OK;
     c_hi = std::min<uint64_t>(c_hi + 8, m->rb_nb);  // the Gram pipeline prefetches a few cells past a window's end
@@ -1090,20 +1096,27 @@ IMPOP_API int impop_pairwise_scan(impop_ctx *ctx, const impop_matrix *m, const i
     }
     // Chunks of consecutive (in `ord`) windows whose cells fit the Gram scratch (<= ~4 GiB of 288): large
     // chunks keep the persistent Gram grid's last, partially filled round of tasks small next to the launch
-    const bool weighted = !m->wt_prefix.empty();
+    // weighted matrices need a second Gram buffer (the plane partials) only where the planes are NOT walked inside the
+    // Gram task: the int8 kernel, or a window as heavy as 2^24 (launch_gram_any)
+    bool plane_buffer = !m->wt_prefix.empty();
+    if (plane_buffer && gram_planes_in_task()) {
+        uint64_t heaviest = 0;  // a Gram cell is a window or a piece of one: never heavier
+        for (uint64_t i = 0; i < n_windows; ++i) heaviest = std::max(heaviest, window_W(m, windows[i].site_begin, windows[i].site_end));
+        if (heaviest < GRAM_FUSED_WEIGHT_LIMIT) plane_buffer = false;
+    }
     const size_t gram_bytes = (size_t)ld * ld * 4;
-    uint64_t cap = ((weighted ? 2ull : 4ull) << 30) / gram_bytes;  // weighted: a second Gram buffer for the plane partials
+    uint64_t cap = ((plane_buffer ? 2ull : 4ull) << 30) / gram_bytes;
     if (cap < 1) cap = 1;
     if (cap > 4096) cap = 4096;
     void *d = nullptr;
-    const size_t need = 4096 + cap * ((weighted ? 2 : 1) * gram_bytes + sizeof(GramWindow) + 24 + sizeof(Pica2Out) + sizeof(HfstOut) +
+    const size_t need = 4096 + cap * ((plane_buffer ? 2 : 1) * gram_bytes + sizeof(GramWindow) + 24 + sizeof(Pica2Out) + sizeof(HfstOut) +
                                       sizeof(impop_window_stats) + sizeof(impop_pairwise_stats) + 2 * sizeof(GramWindow) + 4 + 3584) + 16 * 256 +
                         (size_t)n * 16 + 8192;
     rc = ctx_scratch(ctx, need, &d);
     if (rc) return fail(rc);
     Carve2 cv(d);
     int32_t *d_g = cv.take<int32_t>(cap * (size_t)ld * ld);
-    int32_t *d_gt = weighted ? cv.take<int32_t>(cap * (size_t)ld * ld) : nullptr;
+    int32_t *d_gt = plane_buffer ? cv.take<int32_t>(cap * (size_t)ld * ld) : nullptr;
     // per-chunk metadata: ONE contiguous region mirrored on the host, so that a chunk costs one host-to-device copy
     // (eight small pageable copies were ~0.3 ms of host time between two Gram launches)
     auto up256 = [](size_t x) { return (x + 255) / 256 * 256; };

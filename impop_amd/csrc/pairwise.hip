@@ -675,13 +675,14 @@ static bool gram_planes_in_task() {
 // Write w_s = sum_k 2^k w_ks with bit planes w_ks in {0,1}.  Masking the site axis with plane k gives a 0/1
 // matrix M_k = M & W_k whose plain Gram matrix is sum_s w_ks b_is b_js (w_ks^2 = w_ks), so
 //     I = sum_k 2^k Gram(M_k)
-// with the same matrix-core kernel: per plane one elementwise AND of the RB32 operand (only the cells the batch
-// touches) and one Gram launch whose epilogue ADDS (count << k) into the sum of the planes before it (integer atomics:
-// a separate shifted-accumulate pass over 4096 x 480^2 counts cost 1.0 ms per plane, twice the Gram launch it followed —
-// tools/bench_weighted.py: 46 -> 19 ms per 4096 node-level windows of 12 planes).  Exact by construction (every partial Gram is
-// an exact integer; the sum is required to stay below 2^31 like the length of an unweighted window); planes
-// without any set bit are skipped, so node lengths below 2^p cost p Gram launches over the NODE-level matrix —
-// against mean-node-length times the MACs for the bp-expanded one.
+// with the same matrix-core pipeline.  Usual case (every window lighter than 2^24): ONE launch, the planes walked inside
+// each task (gram_task_fp4, GramPlanes).  Otherwise, per plane, one elementwise AND of the RB32 operand (only the cells
+// the batch touches) and one Gram launch whose epilogue ADDS (count << k) into the sum of the planes before it (integer
+// atomics; a separate shifted-accumulate pass over 4096 x 480^2 counts cost 1.0 ms per plane, twice the Gram launch it
+// followed).  tools/bench_weighted.py, 4096 node-level windows of 12 planes: 46 ms (separate pass) -> 30 ms (epilogue
+// adds) -> 8.3 ms (planes in the task).  Exact by construction (every partial Gram is an exact integer; the sum is required
+// to stay below 2^31 like the length of an unweighted window); planes without any set bit are skipped, so node lengths
+// below 2^p cost p passes over the NODE-level matrix — against mean-node-length times the MACs for the bp-expanded one.
 __global__ void weight_planes_kernel(const uint32_t *__restrict__ wt, uint64_t n_site, uint64_t n_dword, uint32_t n_plane,
                                      uint32_t *__restrict__ planes, uint32_t *__restrict__ used_bits) {
     const uint64_t d = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;

@@ -226,14 +226,15 @@ __global__ __launch_bounds__(ST) void pica2_adj_kernel(SimBatch batch, const uin
     }
 }
 
+constexpr uint32_t GG_ROWS = 512;  // words of candidate rows a small problem's block may take (the kernels declare them)
 template <bool FROM_ADJ>
 __device__ inline uint32_t greedy_groups_bits(const uint64_t *__restrict__ adj, const SimView &S, const uint32_t *__restrict__ idx,
-                                              double thr, uint32_t m, uint32_t *grp, uint32_t *gsz, uint32_t *rep, uint64_t *rows_big) {
+                                              double thr, uint32_t m, uint32_t *grp, uint32_t *gsz, uint32_t *rep, uint64_t *rows_big,
+                                              uint64_t *rows_small /*LDS, GG_ROWS words (unused with FROM_ADJ)*/) {
     constexpr int JU = 4;               // (candidate, 256-block) items in flight per wave
-    constexpr uint32_t ROWS_S = 512;    // words of candidate rows a small problem's block may take
+    constexpr uint32_t ROWS_S = GG_ROWS;
     __shared__ uint32_t cand[64];
     __shared__ uint32_t sh_n, sh_G;
-    __shared__ uint64_t rows_small[FROM_ADJ ? 1 : ROWS_S];
     if (m == 0) return 0;
     const uint32_t tid = threadIdx.x, lane = tid & 63;
     const uint32_t aw = bit_words(m), nh = aw / 4;
@@ -366,10 +367,10 @@ __device__ inline uint32_t greedy_groups_bits(const uint64_t *__restrict__ adj, 
 
 __device__ inline uint32_t greedy_groups(const SimView &S, const uint32_t *__restrict__ idx, uint32_t m, double thr,
                                          const uint32_t *__restrict__ order, uint32_t *grp, uint32_t *gsz, uint32_t *rep,
-                                         uint32_t *scratch) {
+                                         uint32_t *scratch, uint64_t *rows_s /*LDS, GG_ROWS words*/) {
     // seeds in position order: the blocked form above (same groups, no barrier and round trip per group); the loop below
     // serves a handed-in seed order, where a seed's group may reach below it
-    if (!order && m <= 8192) return greedy_groups_bits<false>(nullptr, S, idx, thr, m, grp, gsz, rep, reinterpret_cast<uint64_t *>(scratch));
+    if (!order && m <= 8192) return greedy_groups_bits<false>(nullptr, S, idx, thr, m, grp, gsz, rep, reinterpret_cast<uint64_t *>(scratch), rows_s);
     const bool by_cutoff = S.gram && S.kind == IMPOP_IDENTITY_MATCH;
     const int64_t hstar = by_cutoff ? match_cutoff(S, thr) : 0;
     __shared__ uint32_t chunk_cnt[ST];
@@ -487,9 +488,10 @@ __global__ __launch_bounds__(ST, 5) void pica2_kernel(SimBatch batch, const uint
         __syncthreads();
     }
     // Step 1 (pica2.py:94-112)
+    __shared__ __attribute__((aligned(8))) uint64_t rows_s[GG_ROWS];  // Step 1: candidate rows; Step 2: the groups' frequencies
     const uint32_t G = split.adj ? greedy_groups_bits<true>(split.adj + prob * (uint64_t)n_el * bit_words(n_el), S, idx, threshold, n_el,
-                                                            grp, gsz, rep, reinterpret_cast<uint64_t *>(rowsum))
-                                 : greedy_groups(S, idx, n_el, threshold, order, grp, gsz, rep, reinterpret_cast<uint32_t *>(rowsum));
+                                                            grp, gsz, rep, reinterpret_cast<uint64_t *>(rowsum), rows_s)
+                                 : greedy_groups(S, idx, n_el, threshold, order, grp, gsz, rep, reinterpret_cast<uint32_t *>(rowsum), rows_s);
     if (!memo_first && G >= 48) {  // many groups: the G(G-1)/2 representative pairs then cost a look-up each
         sim_table_fill(S, sim_tbl, ST);
         __syncthreads();
@@ -528,6 +530,14 @@ __global__ __launch_bounds__(ST, 5) void pica2_kernel(SimBatch batch, const uint
         // (a thread per row read one cache line per lane and pair: 4096 singleton groups cost 94 ms per window) —
         // lane partials in j order, fixed butterfly across lanes
         const uint32_t lane = tid & 63;
+        // f_g = size / total once per group instead of a double-precision division per PAIR (the same quotient); the
+        // table takes the candidate-row words of Step 1.  (Fewer instructions, no measurable change at 465 groups per
+        // window: 4.9 ms per 4096 windows either way — the rows' Gram loads bound this loop, not its arithmetic.)
+        double *ftab = G <= GG_ROWS ? reinterpret_cast<double *>(rows_s) : nullptr;
+        if (ftab) {
+            for (uint32_t g = tid; g < G; g += ST) ftab[g] = (double)gsz[g] / total;
+            __syncthreads();
+        }
         for (uint32_t i = tid >> 6; i < G; i += ST / 64) {
             const uint32_t ri = idx ? idx[rep[i]] : rep[i];
             const double fi = (double)gsz[i] / total;
@@ -545,7 +555,7 @@ __global__ __launch_bounds__(ST, 5) void pica2_kernel(SimBatch batch, const uint
                     const uint32_t j = j0 + 64 * u;
                     const double s = sv[u];
                     if (j >= G || s != s) continue;
-                    const double fj = (double)gsz[j] / total;
+                    const double fj = ftab ? ftab[j] : (double)gsz[j] / total;
                     acc += 2 * ((1 - s) * fi * fj);
                     have = 1;
                     ++npairs;
@@ -862,8 +872,9 @@ __global__ __launch_bounds__(ST, 5) void hud_grouped_kernel(SimBatch batch, cons
     const uint64_t prob = blockIdx.x;
     const SimView S = sim_view(batch, prob);
     const uint32_t tid = threadIdx.x;
-    const uint32_t GA = greedy_groups(S, ia, ma, threshold, order_a, grpA, szA, repA, reinterpret_cast<uint32_t *>(rowsum));
-    const uint32_t GB = greedy_groups(S, ib, mb, threshold, order_b, grpB, szB, repB, reinterpret_cast<uint32_t *>(rowsum));
+    __shared__ __attribute__((aligned(8))) uint64_t rows_s[GG_ROWS];
+    const uint32_t GA = greedy_groups(S, ia, ma, threshold, order_a, grpA, szA, repA, reinterpret_cast<uint32_t *>(rowsum), rows_s);
+    const uint32_t GB = greedy_groups(S, ib, mb, threshold, order_b, grpB, szB, repB, reinterpret_cast<uint32_t *>(rowsum), rows_s);
     if (tid < 3) sh_miss[tid] = 0;
     __syncthreads();
     // within A, within B (hud.py:101-128), then between (hud.py:235-263): one pass each
@@ -1014,13 +1025,23 @@ __global__ void py_round_kernel(const double *__restrict__ x, uint64_t count, in
     if (i < count) out[i] = py_round(x[i], nd);
 }
 
+// dynamic LDS a kernel may ask for: the 160 KB of a CDNA4 workgroup minus what its static arrays take (and 1 KB of slack)
+static size_t dynamic_lds_room(const void *kernel) {
+    hipFuncAttributes fa;
+    if (hipFuncGetAttributes(&fa, kernel) != hipSuccess) return 128 * 1024;
+    const size_t total = 160 * 1024, used = fa.sharedSizeBytes + 1024;
+    return used < total ? total - used : 0;
+}
+
 int launch_pica2(impop_ctx *ctx, const SimBatch &b, uint64_t n_problems, const uint32_t *d_idx, uint32_t n_el,
                  const uint32_t *d_order, double threshold, const uint64_t *d_seq_len, Pica2Out *d_out,
                  uint32_t *d_group_of) {
     if (!n_problems) return IMPOP_OK;
     const size_t lds = (size_t)n_el * (8 + 12) + (b.gram ? (size_t)b.n * 4 : 0) + 16;
-    // 160 KB per workgroup, of which ~10 KB are the kernel's static arrays (identity memo, scan counters)
-    REQUIRE(lds <= 148 * 1024, "pica2: %u elements exceed the LDS-resident grouping limit (7500; 6300 on Gram problems)", n_el);
+    // 160 KB per workgroup, minus the kernel's static arrays (identity memo, candidate rows of the grouping, counters:
+    // ~14 KB) — asked of the runtime, so that the limit follows the kernel
+    static const size_t lds_room = dynamic_lds_room((const void *)pica2_kernel);
+    REQUIRE(lds <= lds_room, "pica2: %u elements exceed the LDS-resident grouping limit (about 7300; 6100 on Gram problems)", n_el);
     REQUIRE(n_problems < 0x7FFFFFFFull, "pica2: too many problems");
     // few large problems: Step 2 is split over row chunks (about 8 workgroups per CU in total, >= 16 rows each)
     uint32_t chunks = 1;
@@ -1103,7 +1124,8 @@ int launch_hud_grouped(impop_ctx *ctx, const SimBatch &b, uint64_t n_problems, c
     if (!n_problems) return IMPOP_OK;
     REQUIRE(n_problems < 0x7FFFFFFFull, "grouped Fst: too many problems");
     const size_t lds = (size_t)std::max(ma, mb) * 8 + ((size_t)ma + mb) * 12 + 16;
-    REQUIRE(lds <= 150 * 1024, "grouped Fst: populations too large for the LDS-resident grouping");
+    static const size_t lds_room = dynamic_lds_room((const void *)hud_grouped_kernel);
+    REQUIRE(lds <= lds_room, "grouped Fst: populations too large for the LDS-resident grouping");
     if (lds > 48 * 1024)
         HIP_TRY(hipFuncSetAttribute((const void *)hud_grouped_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(hud_grouped_kernel, dim3((uint32_t)n_problems), dim3(ST), lds, ctx->stream, b, d_ia, ma, d_ib, mb,

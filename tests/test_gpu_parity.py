@@ -1131,6 +1131,24 @@ def test_weighted_gram_equals_bp_expanded_matrix(ctx, oracle):
     big.free()
 
 
+def test_pica2_at_and_beyond_the_lds_limit(ctx, oracle):
+    """The grouping state of a problem lives in LDS: 160 KB minus the kernel's static arrays (asked of the runtime).  A dense
+    table just inside the limit runs (and agrees with the oracle); one beyond it is refused with an error, not launched."""
+    import impop_amd
+    rng = np.random.default_rng(3)
+    n = 7000
+    g = rng.integers(0, 9, size=n)
+    sim = np.where(g[:, None] == g[None, :], 0.9995, 0.9).astype(np.float64)
+    sim[np.arange(n), np.arange(n)] = 1.0
+    pi, ps, grp, G = ctx.pi_from_identity(sim, 0.999, 5, 50000)
+    opi, ops, ogrp, oG = oracle.pica2(sim, 0.999, 50000, 5)
+    assert G == oG == 9 and (grp == ogrp).all() and rel_close(pi, opi, REL, 1e-300)
+    del sim
+    big = np.ones((7700, 7700))
+    with pytest.raises(impop_amd.ImpopError, match="LDS-resident"):
+        ctx.pi_from_identity(big, 0.999, 5, 50000)
+
+
 def test_weighted_gram_plane_walks(ctx):
     """The two ways the weight planes are walked: inside one task (Horner on the fp32 accumulators; windows lighter than
     2^24) — with unused planes between used ones, a single used plane, only high planes — and one launch per plane with

@@ -633,23 +633,40 @@ __global__ void scan_multi_finalize_kernel(const uint64_t *__restrict__ parts, c
 // grid (chunks of 4096 sites, windows); LDS histogram per workgroup, integer atomics to the output.
 __global__ __launch_bounds__(256) void afs_kernel(const uint32_t *__restrict__ sb, const uint32_t *__restrict__ mask,
                                                   uint32_t wps, uint32_t G, uint32_t r, const impop_window *__restrict__ wins,
-                                                  uint32_t bins, uint32_t *__restrict__ out) {
+                                                  uint32_t bins, uint64_t chunk_sites, uint32_t *__restrict__ out) {
     extern __shared__ uint32_t hist[];
     const impop_window w = wins[blockIdx.y];
-    const uint64_t c0 = w.site_begin + (uint64_t)blockIdx.x * 4096;
+    const uint64_t c0 = w.site_begin + (uint64_t)blockIdx.x * chunk_sites;
     if (c0 >= w.site_end) return;  // uniform per workgroup
-    const uint64_t c1 = c0 + 4096 < w.site_end ? c0 + 4096 : w.site_end;
+    const uint64_t c1 = c0 + chunk_sites < w.site_end ? c0 + chunk_sites : w.site_end;
     for (uint32_t i = threadIdx.x; i < bins; i += 256) hist[i] = 0;
     __syncthreads();
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // Most sites of a real matrix are carried by nobody or by everybody: those two bins are counted per WAVE (a ballot
+    // and a popcount, one LDS add by one lane) — 64 lanes adding to the same LDS word one after the other was what this
+    // kernel spent its time on; the bins in between keep their per-lane atomics (few lanes, spread over many words).
+    uint32_t n_zero = 0, n_full = 0;
     for (uint64_t b = (c0 >> 6) + wave; b <= ((c1 - 1) >> 6); b += 4) {
         const uint64_t s = b * 64 + lane;
-        if (s < c0 || s >= c1) continue;
-        atomicAdd(&hist[masked_site_count(sb + b * 64ull * wps, mask, G, r, lane)], 1u);
+        const bool in = s >= c0 && s < c1;
+        const uint32_t c = masked_site_count(sb + b * 64ull * wps, mask, G, r, lane);
+        const bool zero = in && c == 0, full = in && c == bins - 1;
+        n_zero += (uint32_t)__popcll(__ballot(zero));
+        n_full += (uint32_t)__popcll(__ballot(full));
+        if (in && !zero && !full) atomicAdd(&hist[c], 1u);
+    }
+    if (lane == 0) {
+        if (n_zero) atomicAdd(&hist[0], n_zero);
+        if (n_full) atomicAdd(&hist[bins - 1], n_full);  // bins == 1 (empty mask): the same word, and n_full is 0 (c == 0 is `zero`)
     }
     __syncthreads();
-    for (uint32_t i = threadIdx.x; i < bins; i += 256)
-        if (hist[i]) atomicAdd(&out[(uint64_t)blockIdx.y * bins + i], hist[i]);
+    uint32_t *o = out + (uint64_t)blockIdx.y * bins;
+    if (gridDim.x == 1) {  // the window's only workgroup: its histogram IS the result
+        for (uint32_t i = threadIdx.x; i < bins; i += 256) o[i] = hist[i];
+    } else {
+        for (uint32_t i = threadIdx.x; i < bins; i += 256)
+            if (hist[i]) atomicAdd(&o[i], hist[i]);
+    }
 }
 
 // mask bitset (uint64 words, n bits) -> wps dwords clipped to n; NULL -> `fill`
@@ -1195,7 +1212,12 @@ IMPOP_API int impop_afs(impop_ctx *ctx, const impop_matrix *m, const impop_windo
     HIP_TRY(hipMemcpyAsync(base + o_mask, mk.data(), (size_t)m->g.wps * 4, hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(hipMemcpyAsync(base + o_wins, windows, n_windows * sizeof(impop_window), hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(hipMemsetAsync(base + o_out, 0, n_windows * bins * 4, ctx->stream));
-    const uint64_t chunks = (longest + 4095) / 4096;
+    // a workgroup per window when there are thousands of them (one flush of the histogram per window, no atomics), more —
+    // never shorter than 4096 sites — when few windows would leave CUs idle (about 32 workgroups per CU wanted)
+    const uint64_t want = 32ull * (uint64_t)(ctx->n_cu > 0 ? ctx->n_cu : 256);
+    uint64_t chunks = std::min<uint64_t>((longest + 4095) / 4096, std::max<uint64_t>(1, (want + n_windows - 1) / std::max<uint64_t>(n_windows, 1)));
+    const uint64_t chunk_sites = chunks ? ((longest + chunks - 1) / chunks + 63) / 64 * 64 : 0;
+    if (chunks) chunks = (longest + chunk_sites - 1) / chunk_sites;
     if (chunks) {
         REQUIRE(chunks < 0x7FFFFFFFull, "impop_afs: window too long");
         // windows ride on gridDim.y (<= 65535): any number of windows goes out in batches of that many
@@ -1203,7 +1225,7 @@ IMPOP_API int impop_afs(impop_ctx *ctx, const impop_matrix *m, const impop_windo
             const uint32_t nw = (uint32_t)std::min<uint64_t>(65535, n_windows - w0);
             hipLaunchKernelGGL(afs_kernel, dim3((uint32_t)chunks, nw), dim3(256), (size_t)bins * 4, ctx->stream, m->d_sb,
                                (const uint32_t *)(base + o_mask), m->g.wps, m->g.G, m->g.r,
-                               (const impop_window *)(base + o_wins) + w0, bins, (uint32_t *)(base + o_out) + w0 * bins);
+                               (const impop_window *)(base + o_wins) + w0, bins, chunk_sites, (uint32_t *)(base + o_out) + w0 * bins);
             HIP_TRY(hipGetLastError());
         }
     }

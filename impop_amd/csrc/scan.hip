@@ -650,14 +650,14 @@ __global__ __launch_bounds__(256) void afs_kernel(const uint32_t *__restrict__ s
         const uint64_t s = b * 64 + lane;
         const bool in = s >= c0 && s < c1;
         const uint32_t c = masked_site_count(sb + b * 64ull * wps, mask, G, r, lane);
-        const bool zero = in && c == 0, full = in && c == bins - 1;
+        const bool zero = in && c == 0, full = in && !zero && c == bins - 1;  // an empty mask has ONE bin: count it once
         n_zero += (uint32_t)__popcll(__ballot(zero));
         n_full += (uint32_t)__popcll(__ballot(full));
         if (in && !zero && !full) atomicAdd(&hist[c], 1u);
     }
     if (lane == 0) {
         if (n_zero) atomicAdd(&hist[0], n_zero);
-        if (n_full) atomicAdd(&hist[bins - 1], n_full);  // bins == 1 (empty mask): the same word, and n_full is 0 (c == 0 is `zero`)
+        if (n_full) atomicAdd(&hist[bins - 1], n_full);
     }
     __syncthreads();
     uint32_t *o = out + (uint64_t)blockIdx.y * bins;

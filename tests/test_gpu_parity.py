@@ -432,6 +432,22 @@ def test_afs_matches_numpy(ctx):
             assert (g == np.bincount(c, minlength=nP + 1)).all()
             assert int(g.sum()) == s1 - s0
     bm.free()
+    # thousands of windows: one workgroup per window stores its histogram directly; columns nobody / everybody carries
+    # (the two bins counted per wave) next to ordinary ones, windows that start and end inside 64-site blocks
+    m2 = m.copy()
+    m2[:, rng.random(W) < 0.3] = 0
+    m2[:, rng.random(W) < 0.3] = 1
+    bm = ctx.upload_dense(m2)
+    starts = np.sort(rng.integers(0, W - 70, size=9000))
+    wins = [(int(a), int(a + rng.integers(1, 70))) for a in starts]
+    for mask, rows in ((None, np.ones(n, bool)), (sub, sub.astype(bool)), (np.zeros(n, np.uint8), np.zeros(n, bool))):
+        got = bm.afs(wins, mask)
+        nP = int(rows.sum())
+        cs = m2[rows].sum(0) if nP else np.zeros(W, dtype=np.int64)
+        for (s0, s1), g in zip(wins[::37], got[::37]):
+            assert (g == np.bincount(cs[s0:s1], minlength=nP + 1)).all(), (s0, s1, nP)
+        assert (got.sum(axis=1) == np.array([b - a for a, b in wins])).all()
+    bm.free()
 
 
 def test_matrix_free_refused_while_plan_alive(ctx):

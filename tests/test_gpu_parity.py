@@ -1196,6 +1196,18 @@ def test_weighted_gram_plane_walks(ctx):
             assert r.tobytes() == one.tobytes(), (name, a, b)
             assert int(r["n_sites"]) == L
     bm.free()
+    # one long window: the site axis is split over K-slices (atomic adds of the slices' results), every slice walks the planes
+    n, K = 40, 200_000
+    m = (rng.random((n, K)) < rng.random(K)).astype(np.uint8)
+    w = rng.integers(0, 41, size=K).astype(np.uint32)          # zero weights too: such a column counts for nothing
+    bm = ctx.upload_dense(m, keep_hap_major=True)
+    bm.set_site_weights(w)
+    mi = m.astype(np.int64)
+    for a, b in ((0, K), (12345, 187_654)):
+        want = (mi[:, a:b] * w[a:b].astype(np.int64)) @ mi[:, a:b].T
+        assert want.max() < 2 ** 24
+        assert (bm.pairwise_counts(a, b).astype(np.int64) == want).all(), (a, b)
+    bm.free()
 
 
 def test_config5_full_size_gram_and_scan_properties(ctx):

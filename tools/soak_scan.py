@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Soak test (not part of the suite): random matrices / windows / masks through the streaming scan, the
-compacted-matrix scan and the K-population scan, checked against the oracle's site-count formulation."""
+compacted-matrix scan, the K-population scan, the allele-frequency spectrum and per-site counts, checked against the
+oracle's site-count formulation / numpy."""
 import os
 import sys
 import time
@@ -57,6 +58,21 @@ while time.time() < t_end:
                     x, y = pr[:, p][k], two[k]
                     assert ((x == y) | (np.isnan(x) & np.isnan(y))).all(), (n, W, i, j, k)
                 p += 1
+    # allele-frequency spectrum and per-site counts of the same windows against numpy (few windows: several workgroups
+    # per window; every few iterations thousands of short windows: one workgroup per window)
+    rows = np.ones(n, bool) if inP is None else inP.astype(bool)
+    cs = m[rows].sum(0).astype(np.int64) if rows.any() else np.zeros(W, np.int64)
+    aw = [(a, b) for a, b, _ in wins]
+    if it % 5 == 0 and W > 80:
+        st = np.sort(rng.integers(0, W - 70, size=8300))
+        aw = [(int(a), int(a + rng.integers(0, 70))) for a in st]
+    spec = bm.afs(aw, inP)
+    for (a, b), g in list(zip(aw, spec))[:: max(1, len(aw) // 40)]:
+        assert (g == np.bincount(cs[a:b], minlength=int(rows.sum()) + 1)).all(), (n, W, a, b, "afs")
+    assert (spec.sum(axis=1) == np.array([b - a for a, b in aw])).all(), (n, W, "afs totals")
+    a, b = wins[0][0], wins[0][1]
+    if b > a:
+        assert (bm.site_counts(a, b, inP).astype(np.int64) == cs[a:b]).all(), (n, W, a, b, "site counts")
     bm.free()
     it += 1
     if it % 20 == 0:

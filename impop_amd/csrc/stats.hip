@@ -262,6 +262,8 @@ __device__ inline uint32_t greedy_groups_bits(const uint64_t *__restrict__ adj, 
     for (;;) {
         uint32_t mycand = 0;  // wave 0: lane b holds candidate b
         if (tid < 64) {  // the next up-to-B free positions, ascending: uniform work on words read across the lanes
+            // the serial stretches of one wave: ahead of the other problems' waves on this SIMD while they last
+            __builtin_amdgcn_s_setprio(3);
             uint32_t n = 0;
             bool first = true;
             // (h_first lives across the workgroup-wide loop in a vector register: tell the compiler it is one value per wave,
@@ -285,6 +287,7 @@ __device__ inline uint32_t greedy_groups_bits(const uint64_t *__restrict__ adj, 
             }
             if (lane < n) cand[lane] = mycand;
             if (lane == 0) sh_n = n;
+            __builtin_amdgcn_s_setprio(0);
         }
         __syncthreads();
         const uint32_t n = __builtin_amdgcn_readfirstlane(sh_n);
@@ -335,6 +338,7 @@ __device__ inline uint32_t greedy_groups_bits(const uint64_t *__restrict__ adj, 
         }
         __syncthreads();
         if (tid < 64) {
+            __builtin_amdgcn_s_setprio(3);
             // rows do not depend on the state of the grouping: the next candidate's words are read while this one is resolved
             uint64_t r0 = lane < aw ? rows[lane] : 0, r1 = lane + 64 < aw ? rows[lane + 64] : 0;
             for (uint32_t b = 0; b < n; ++b) {
@@ -358,6 +362,7 @@ __device__ inline uint32_t greedy_groups_bits(const uint64_t *__restrict__ adj, 
                 ++G;
             }
             if (lane == 0) sh_G = G;
+            __builtin_amdgcn_s_setprio(0);
         }
         __syncthreads();
         G = __builtin_amdgcn_readfirstlane(sh_G);

@@ -7,9 +7,10 @@
  * What the serial window loops of run_tajd.sh:103-196 / run_h-fst.sh:155-190 become on a multi-GPU node: the
  * window list is cut into contiguous ranges (impop_shard_windows), every shard's slab of sites is uploaded to its
  * own context — one per device when the machine has as many devices as shards, otherwise several contexts share
- * device 0 — impop_scan_sharded runs all of them and returns the records in window order.  The result is compared
- * byte for byte with one context holding the whole matrix, and the same records are pushed through the
- * one-process-per-GPU exchange (impop_comm_* + impop_gather_records over RCCL) with a one-rank communicator. */
+ * device 0 — impop_scan_sharded runs all of them and returns the records in window order; impop_pairwise_scan_sharded
+ * does the same for the all-pairs mode (thresholded pica2 + h-fst).  Both results are compared byte for byte with one
+ * context holding the whole matrix, and the scan records are pushed through the one-process-per-GPU exchange
+ * (impop_comm_* + impop_gather_records over RCCL) with a one-rank communicator. */
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -55,7 +56,7 @@ int main(int argc, char **argv) {
     impop_matrix *whole = NULL;
     static impop_window_stats want[64], got[64], gathered[64];
     CHECK(impop_ctx_create(0, NULL, &ctx0));
-    CHECK(impop_matrix_upload(ctx0, &bits[0][0], N_HAP, N_SITE, WORDS, IMPOP_KEEP_SITE_BLOCKED, &whole));
+    CHECK(impop_matrix_upload(ctx0, &bits[0][0], N_HAP, N_SITE, WORDS, IMPOP_KEEP_SITE_BLOCKED | IMPOP_KEEP_HAP_MAJOR, &whole));
     CHECK(impop_scan(ctx0, whole, win, n_win, NULL, &mask_a, &mask_b, NULL, want));
 
     /* shards: a context + the slab its windows touch, per shard */
@@ -71,7 +72,8 @@ int main(int argc, char **argv) {
         /* slab = whole 64-bit words of the hap-major rows around [s0, s1) */
         const uint64_t w0 = s0 / 64, w1 = (s1 + 63) / 64 > w0 ? (s1 + 63) / 64 : w0 + 1;
         uint64_t n_slab_site = (w1 * 64 < N_SITE ? w1 * 64 : N_SITE) - w0 * 64;
-        CHECK(impop_matrix_upload(ctxs[k], &bits[0][w0], N_HAP, n_slab_site, WORDS, IMPOP_KEEP_SITE_BLOCKED, &slabs[k]));
+        CHECK(impop_matrix_upload(ctxs[k], &bits[0][w0], N_HAP, n_slab_site, WORDS, IMPOP_KEEP_SITE_BLOCKED | IMPOP_KEEP_HAP_MAJOR,
+                                  &slabs[k]));
         slab_begin[k] = w0 * 64;
         printf("shard %d on device %d: windows [%llu, %llu), sites [%llu, %llu)\n", k, n_dev >= n_shards ? k : 0,
                (unsigned long long)first, (unsigned long long)(first + cnt), (unsigned long long)s0, (unsigned long long)s1);
@@ -81,6 +83,18 @@ int main(int argc, char **argv) {
     const int same = memcmp(want, got, n_win * sizeof want[0]) == 0;
     printf("%llu windows over %d shards: records %s one context's\n", (unsigned long long)n_win, n_shards,
            same ? "byte-identical to" : "DIFFER from");
+
+    /* the all-pairs mode (pica2 -t 0.999 -r 5 + h-fst per window) over the same shards */
+    static impop_pairwise_stats pw_want[64], pw_got[64];
+    impop_pairwise_params pp;
+    memset(&pp, 0, sizeof pp);
+    pp.struct_size = sizeof pp; pp.identity_kind = IMPOP_IDENTITY_MATCH; pp.threshold = 0.999; pp.round_digits = 5;
+    CHECK(impop_pairwise_scan(ctx0, whole, win, n_win, NULL, &mask_a, &mask_b, &pp, pw_want));
+    CHECK(impop_pairwise_scan_sharded(ctxs, (const impop_matrix *const *)slabs, slab_begin, n_shards, win, n_win, NULL, &mask_a,
+                                      &mask_b, &pp, pw_got));
+    const int same3 = memcmp(pw_want, pw_got, n_win * sizeof pw_want[0]) == 0;
+    printf("all-pairs mode over %d shards: records %s one context's (window 0: %u groups, pi %.8f)\n", n_shards,
+           same3 ? "byte-identical to" : "DIFFER from", pw_got[0].n_groups, pw_got[0].pi_site);
 
     /* the one-process-per-GPU exchange with the one rank this process is */
     unsigned char id[IMPOP_COMM_ID_BYTES];
@@ -103,5 +117,5 @@ int main(int argc, char **argv) {
     }
     CHECK(impop_matrix_free(ctx0, whole));
     CHECK(impop_ctx_destroy(ctx0));
-    return same && same2 ? 0 : 1;
+    return same && same2 && same3 ? 0 : 1;
 }

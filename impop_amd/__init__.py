@@ -8,7 +8,7 @@ entry point raises ImpopError.
 """
 from ._lib import ImpopError, SO_PATH  # noqa: F401
 from . import distributed  # noqa: F401
-from .engine import (Comm, scan_sharded, shard_windows_c,  # noqa: F401
+from .engine import (Comm, pairwise_scan_sharded, scan_sharded, shard_windows_c,  # noqa: F401
                      BitMatrix, Context, ScanPlan, STATS_DTYPE, PAIRWISE_DTYPE, WINDOW_DTYPE, fixed_windows,  # noqa: F401
                      make_windows, mask_from_indices, pack_hap_major, pack_mask, unpack_hap_major)
 

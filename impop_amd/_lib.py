@@ -107,6 +107,8 @@ SIGNATURES = {
     "impop_shard_windows": (C.c_int, [C.POINTER(Window), C.c_uint64, C.c_int, C.c_int, _u64p, _u64p, _u64p, _u64p]),
     "impop_scan_sharded": (C.c_int, [C.POINTER(_vp), C.POINTER(_vp), _u64p, C.c_int, C.POINTER(Window), C.c_uint64, _u64p, _u64p,
                                      _u64p, C.POINTER(ScanParams), C.POINTER(WindowStats)]),
+    "impop_pairwise_scan_sharded": (C.c_int, [C.POINTER(_vp), C.POINTER(_vp), _u64p, C.c_int, C.POINTER(Window), C.c_uint64, _u64p,
+                                              _u64p, _u64p, C.POINTER(PairwiseParams), C.POINTER(PairwiseStats)]),
     "impop_comm_unique_id": (C.c_int, [C.c_char_p]),
     "impop_comm_create": (C.c_int, [_vp, C.c_char_p, C.c_int, C.c_int, C.POINTER(_vp)]),
     "impop_comm_destroy": (C.c_int, [_vp]),

@@ -16,6 +16,8 @@
 #include <string.h>
 
 #include <algorithm>
+#include <string>
+#include <thread>
 #include <vector>
 
 #include "internal.h"
@@ -103,6 +105,58 @@ IMPOP_API int impop_scan_sharded(impop_ctx *const *ctxs, const impop_matrix *con
             if (rc) { cleanup(); return rc; }
         }
     cleanup();
+    return IMPOP_OK;
+}
+
+// The all-pairs mode over several devices: impop_pairwise_scan waits for its own results (chunks of Gram matrices go
+// through one scratch), so every context's shard runs on a host thread of its own; the devices work side by side.
+IMPOP_API int impop_pairwise_scan_sharded(impop_ctx *const *ctxs, const impop_matrix *const *slabs, const uint64_t *slab_site_begin,
+                                          int n_ctx, const impop_window *windows, uint64_t n_windows, const uint64_t *mask_p,
+                                          const uint64_t *mask_a, const uint64_t *mask_b, const impop_pairwise_params *params,
+                                          impop_pairwise_stats *out_host) {
+    REQUIRE(ctxs && slabs && slab_site_begin && n_ctx >= 1 && params, "impop_pairwise_scan_sharded: NULL argument or n_ctx < 1");
+    REQUIRE(n_windows == 0 || (windows && out_host), "impop_pairwise_scan_sharded: NULL windows/out");
+    std::vector<uint64_t> first((size_t)n_ctx, 0), count((size_t)n_ctx, 0);
+    std::vector<std::vector<impop_window>> loc((size_t)n_ctx);
+    for (int k = 0; k < n_ctx; ++k) {
+        REQUIRE(ctxs[k] && slabs[k], "impop_pairwise_scan_sharded: context or slab %d is NULL", k);
+        for (int j = 0; j < k; ++j)
+            REQUIRE(ctxs[j] != ctxs[k], "impop_pairwise_scan_sharded: contexts %d and %d are the same (a context serves one shard at a time)", j, k);
+        uint64_t s0 = 0, s1 = 0;
+        const int rc = impop_shard_windows(windows, n_windows, n_ctx, k, &first[k], &count[k], &s0, &s1);
+        if (rc) return rc;
+        if (!count[k]) continue;
+        uint64_t n_site = 0;
+        impop_matrix_info(slabs[k], nullptr, &n_site, nullptr, nullptr);
+        if (slabs[k]->compact || s0 < slab_site_begin[k] || s1 > slab_site_begin[k] + n_site) {
+            set_error("impop_pairwise_scan_sharded: slab %d ([%llu, %llu)%s) does not cover its windows' sites [%llu, %llu)", k,
+                      (unsigned long long)slab_site_begin[k], (unsigned long long)(slab_site_begin[k] + n_site),
+                      slabs[k]->compact ? ", compacted" : "", (unsigned long long)s0, (unsigned long long)s1);
+            return IMPOP_E_INVALID;
+        }
+        loc[k].assign(windows + first[k], windows + first[k] + count[k]);
+        for (impop_window &w : loc[k]) { w.site_begin -= slab_site_begin[k]; w.site_end -= slab_site_begin[k]; }
+    }
+    std::vector<int> rcs((size_t)n_ctx, IMPOP_OK);
+    std::vector<std::string> msgs((size_t)n_ctx);
+    auto work = [&](int k) {
+        rcs[k] = impop_pairwise_scan(ctxs[k], slabs[k], loc[k].data(), count[k], mask_p, mask_a, mask_b, params, out_host + first[k]);
+        if (rcs[k]) msgs[k] = impop_last_error();  // the message lives in the worker's thread: carry it over
+    };
+    std::vector<std::thread> th;
+    int own = -1;
+    for (int k = 0; k < n_ctx; ++k) {
+        if (!count[k]) continue;
+        if (own < 0) own = k;  // the first shard runs on the calling thread
+        else th.emplace_back(work, k);
+    }
+    if (own >= 0) work(own);
+    for (std::thread &t : th) t.join();
+    for (int k = 0; k < n_ctx; ++k)
+        if (rcs[k]) {
+            set_error("impop_pairwise_scan_sharded: shard %d: %s", k, msgs[k].c_str());
+            return rcs[k];
+        }
     return IMPOP_OK;
 }
 

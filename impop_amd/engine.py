@@ -519,6 +519,31 @@ def scan_sharded(slabs, slab_site_begin, windows, mask_p=None, mask_a=None, mask
     return out
 
 
+def pairwise_scan_sharded(slabs, slab_site_begin, windows, mask_p=None, mask_a=None, mask_b=None, kind: str = "match",
+                          threshold: float = 0.99, round_digits: Optional[int] = None, d_pi_mode: int = 0, s_scope: int = 0,
+                          fst_method: str = "direct") -> np.ndarray:
+    """The all-pairs mode over several contexts (impop_pairwise_scan_sharded): like scan_sharded, with
+    BitMatrix.pairwise_scan's parameters; every slab needs its hap-major operand (keep_hap_major=True)."""
+    lib = _lib.load()
+    w = make_windows(windows)
+    n = len(slabs)
+    n_hap = slabs[0].n_hap
+    ctxs = (C.c_void_p * n)(*[s.ctx.handle for s in slabs])
+    mats = (C.c_void_p * n)(*[s.handle for s in slabs])
+    begins = np.ascontiguousarray(slab_site_begin, dtype=np.uint64)
+    prm = PairwiseParams(C.sizeof(PairwiseParams), IDENTITY_KINDS[kind], float(threshold),
+                         -1 if round_digits is None else int(round_digits), int(d_pi_mode), int(s_scope),
+                         {"direct": 0, "grouped": 1}[fst_method])
+    kp, pp = _mask_ptr(mask_p, n_hap)
+    ka, pa = _mask_ptr(mask_a, n_hap)
+    kb, pb = _mask_ptr(mask_b, n_hap)
+    out = np.zeros(len(w), dtype=PAIRWISE_DTYPE)
+    check(lib.impop_pairwise_scan_sharded(ctxs, mats, begins.ctypes.data_as(C.POINTER(C.c_uint64)), n,
+                                          w.ctypes.data_as(C.POINTER(Window)), len(w), pp, pa, pb, C.byref(prm),
+                                          out.ctypes.data_as(C.POINTER(PairwiseStats))))
+    return out
+
+
 def _preload_torch_rccl() -> None:
     """One RCCL per process: if PyTorch-ROCm is installed, load ITS librccl (soname librccl.so.1) first, by path,
     so that the library's dlopen("librccl.so.1") and a later `import torch` bind to the same copy."""

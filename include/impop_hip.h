@@ -311,6 +311,18 @@ int impop_pairwise_scan(impop_ctx *ctx, const impop_matrix *m, const impop_windo
                         const uint64_t *mask_p, const uint64_t *mask_a, const uint64_t *mask_b,
                         const impop_pairwise_params *params, impop_pairwise_stats *out_host);
 
+/* impop_pairwise_scan over several devices, sharded like impop_scan_sharded (declared with the multi-GPU entry points
+ * above; run_pica2_impg.sh:125-236 / run_h-fst.sh:155-190 with thresholds):
+ * shard k = the windows impop_shard_windows gives it, contracted on ctxs[k] from slabs[k] (which needs its hap-major
+ * operand, IMPOP_KEEP_HAP_MAJOR).  Every shard runs on a host thread of its own, so the devices work side by side;
+ * contexts must be distinct.  out_host: n_windows records in the order of `windows`, byte for byte what one context
+ * holding the whole matrix returns. */
+int impop_pairwise_scan_sharded(impop_ctx *const *ctxs, const impop_matrix *const *slabs, const uint64_t *slab_site_begin,
+                                int n_ctx, const impop_window *windows, uint64_t n_windows, const uint64_t *mask_p,
+                                const uint64_t *mask_a, const uint64_t *mask_b, const impop_pairwise_params *params,
+                                impop_pairwise_stats *out_host);
+
+
 /* ---- statistics on a given identity matrix (the .sim drop-in path) ---------
  * These take what read_similarity_file (pica2.py:6-58, h-fst.py:84-119) yields,
  * densified by the caller, and run the reference's arithmetic on the GPU. */

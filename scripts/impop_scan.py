@@ -83,10 +83,10 @@ def main():
                     "(impop_matrix_compact): identical output, far fewer bytes (and, on the all-pairs path, multiply-adds) per pass")
     ap.add_argument("--device", type=int, default=None, help="default: LOCAL_RANK, else 0")
     ap.add_argument("--devices", type=int, default=1, metavar="N",
-                    help="ONE process driving N GPUs through the C ABI (impop_scan_sharded): the BED rows are cut into N contiguous "
-                         "ranges, each device holds the slab of sites its rows touch, every pass is launched before the first "
-                         "result is fetched; no torch, no launcher.  With fewer than N devices the contexts share device 0. "
-                         "Streaming scan only (not with --panel, --compact or the all-pairs formats)")
+                    help="ONE process driving N GPUs through the C ABI (impop_scan_sharded; impop_pairwise_scan_sharded for the "
+                         "all-pairs formats): the BED rows are cut into N contiguous ranges, each device holds the slab of sites its "
+                         "rows touch, every device works before the first result is fetched; no torch, no launcher.  With fewer "
+                         "than N devices the contexts share device 0.  Not with --panel or --compact")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend when launched with WORLD_SIZE > 1 "
                     "(nccl = RCCL over xGMI; gloo for rehearsals)")
     args = ap.parse_args()
@@ -124,10 +124,6 @@ def main():
     grouped_fst = args.format == "hfst" and args.fst_method == "grouped"
     need_pairwise = grouped_fst or (args.format == "pica2" and ((args.threshold is not None and args.threshold < 1.0)
                                                                  or args.round_digits is not None or args.identity != "match"))
-    if args.devices > 1 and need_pairwise:
-        print("Error: --devices N serves the streaming scan; the all-pairs formats (thresholded / rounded pica2, grouped Fst) run "
-              "on one device or under torch.distributed.run", file=sys.stderr)
-        sys.exit(2)
     multi_dev = args.devices > 1
     all_wins = impop_amd.make_windows(wins)
     if multi_dev:
@@ -206,9 +202,9 @@ def main():
             dist.barrier()
             dist.destroy_process_group()
         return
-    if need_pairwise:
-        # CLI defaults of the reference: pica2.py:175 (-t 0.99), hud.py -t 0.999
-        thr = (0.999 if grouped_fst else 0.99) if args.threshold is None else args.threshold
+    # CLI defaults of the reference: pica2.py:175 (-t 0.99), hud.py -t 0.999
+    thr = (0.999 if grouped_fst else 0.99) if args.threshold is None else args.threshold
+    if need_pairwise and not multi_dev:
         # the pica2 / hfst tables print neither S nor D: s_scope 2 skips the site scan of the all-pairs path
         res = bm.pairwise_scan(wins, mask_p, mask_a, mask_b, kind=args.identity, threshold=thr, round_digits=args.round_digits,
                                s_scope=2, fst_method=args.fst_method if grouped_fst else "direct")
@@ -224,11 +220,16 @@ def main():
             w0, w1 = s0 // 64, max((s1 + 63) // 64, s0 // 64 + 1)
             ck = impop_amd.Context(k if n_dev.value >= args.devices else 0)
             n_slab = max(min(mf.n_site, 64 * w1) - 64 * w0, 0)
-            sk = ck.upload(np.ascontiguousarray(mf.bits[:, w0:w1]), n_slab, keep_hap_major=False)
+            sk = ck.upload(np.ascontiguousarray(mf.bits[:, w0:w1]), n_slab, keep_hap_major=need_pairwise)
             if mf.site_weight is not None:
                 sk.set_site_weights(mf.site_weight[64 * w0: 64 * w0 + n_slab])
             ctxs.append(ck); slabs.append(sk); begins.append(64 * w0)
-        res = engine.scan_sharded(slabs, begins, all_wins, mask_p, mask_a, mask_b)
+        if need_pairwise:  # impop_pairwise_scan_sharded: every device contracts its own windows, a host thread each
+            res = engine.pairwise_scan_sharded(slabs, begins, all_wins, mask_p, mask_a, mask_b, kind=args.identity, threshold=thr,
+                                               round_digits=args.round_digits, s_scope=2,
+                                               fst_method=args.fst_method if grouped_fst else "direct")
+        else:
+            res = engine.scan_sharded(slabs, begins, all_wins, mask_p, mask_a, mask_b)
         for sk, ck in zip(slabs, ctxs):
             sk.free(); ck.close()
     else:

@@ -183,6 +183,13 @@ def test_batch_driver_two_ranks_equal_one(tmp_path):
         assert many.stdout == one.stdout, nd
     bad = subprocess.run([sys.executable] + base + ["--devices", "2", "--compact"], capture_output=True, text=True)
     assert bad.returncode == 2 and "--devices N" in bad.stderr
+    # ... and the all-pairs formats (thresholded pica2, grouped Fst) through impop_pairwise_scan_sharded
+    for extra in (["--format", "pica2", "-t", "0.99", "-r", "4"], ["--format", "hfst", "--fst-method", "grouped", "-t", "0.95"]):
+        ap1 = subprocess.run([sys.executable] + base + extra, capture_output=True, text=True)
+        assert ap1.returncode == 0, ap1.stderr
+        ap3 = subprocess.run([sys.executable] + base + extra + ["--devices", "3"], capture_output=True, text=True)
+        assert ap3.returncode == 0, ap3.stderr
+        assert ap3.stdout == ap1.stdout and len(ap1.stdout.splitlines()) > 10, extra
     # the K-population panel (all pairs per window) sharded the same way
     (tmp_path / "C.txt").write_text("\n".join(f"S{i:03d}" for i in range(15, 20)) + "\n")
     panel = [os.path.join(ROOT, "scripts", "impop_scan.py"), "--matrix", str(tmp_path / "m.npz"), "--bed", str(tmp_path / "w.bed"),

@@ -37,6 +37,7 @@ def test_c_sharded_example_runs(tmp_path, n_shards):
     r = subprocess.run([exe, str(n_shards)], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
     assert f"over {n_shards} shards: records byte-identical to one context's" in r.stdout
+    assert f"all-pairs mode over {n_shards} shards: records byte-identical to one context's" in r.stdout
     assert "RCCL all-gather (1 rank): records intact" in r.stdout
 
 

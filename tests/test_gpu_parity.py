@@ -1003,6 +1003,48 @@ def test_scan_sharded_contexts_equal_one_context():
     whole.free(); c0.close()
 
 
+def test_pairwise_scan_sharded_contexts_equal_one_context():
+    """impop_pairwise_scan_sharded: the all-pairs mode (thresholded pica2 + h-fst / grouped Fst + S + D) over several
+    contexts, each shard on a host thread of its own — records byte-identical to one context holding the whole matrix, for
+    disjoint and sliding windows, a subset mask, a shard count that leaves a shard empty; a slab that does not cover its
+    shard or one context given twice is refused, and an error inside a shard comes back with its text."""
+    import impop_amd
+    from impop_amd import engine
+    n, W = 200, 64 * 150 + 9
+    c0 = impop_amd.Context(0)
+    whole = c0.synthetic(n, W, seed=78, keep_hap_major=True)
+    bits = whole.download()
+    rng = np.random.default_rng(6)
+    inA = (rng.random(n) < 0.3).astype(np.uint8); inB = (rng.random(n) < 0.3).astype(np.uint8)
+    inP = (rng.random(n) < 0.9).astype(np.uint8)
+    for size, step, shards, mp, meth in ((1000, None, 2, None, "direct"), (1000, 500, 3, inP, "direct"), (3000, 1100, 4, None, "grouped"),
+                                         (5000, None, 5, None, "direct")):
+        wins = impop_amd.fixed_windows(W, size, step)
+        want = whole.pairwise_scan(wins, mp, inA, inB, threshold=0.999, round_digits=5, fst_method=meth)
+        ctxs, slabs, begins = [], [], []
+        for k in range(shards):
+            first, cnt, s0, s1 = engine.shard_windows_c(wins, shards, k)
+            w0, w1 = s0 // 64, max((s1 + 63) // 64, s0 // 64 + 1)
+            ck = impop_amd.Context(0)
+            slabs.append(ck.upload(np.ascontiguousarray(bits[:, w0:w1]), min(64 * w1, W) - 64 * w0, keep_hap_major=True))
+            ctxs.append(ck); begins.append(64 * w0)
+        got = impop_amd.pairwise_scan_sharded(slabs, begins, wins, mp, inA, inB, threshold=0.999, round_digits=5, fst_method=meth)
+        assert got.tobytes() == want.tobytes(), (size, step, shards)
+        if shards >= 2:
+            with pytest.raises(impop_amd.ImpopError, match="does not cover"):
+                impop_amd.pairwise_scan_sharded(slabs, [b + 64 for b in begins], wins, mp, inA, inB)
+            with pytest.raises(impop_amd.ImpopError, match="are the same"):
+                impop_amd.pairwise_scan_sharded([slabs[0]] * shards, begins, wins, mp, inA, inB)
+            # an error raised inside a shard's thread (a slab without its hap-major operand) reaches the caller with its text
+            bad = ctxs[1].upload(np.ascontiguousarray(bits[:, begins[1] // 64:]), W - begins[1], keep_hap_major=False)
+            with pytest.raises(impop_amd.ImpopError, match="shard 1"):
+                impop_amd.pairwise_scan_sharded([slabs[0], bad] + slabs[2:], begins, wins, mp, inA, inB)
+            bad.free()
+        for s, ck in zip(slabs, ctxs):
+            s.free(); ck.close()
+    whole.free(); c0.close()
+
+
 def test_rccl_comm_one_rank_gather_and_allreduce():
     """The one-process-per-GPU exchange of the C ABI (impop_comm_* over RCCL, loaded with dlopen) with the one
     rank a one-GPU box allows: all-gather of raw device bytes on the context's stream directly behind the scan

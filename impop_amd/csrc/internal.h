@@ -133,6 +133,9 @@ struct impop_matrix {
     uint64_t n_site_orig = 0;
     std::vector<uint64_t> pos;
     std::vector<uint64_t> pos_coarse;  // pos[k << POS_COARSE_SHIFT]: a cache-resident first level for pos_lower_bound
+    // compacted from a WEIGHTED matrix that kept its hap-major copy (all-pairs path): prefix sums, in ORIGINAL coordinates, of
+    // the weights of the dropped sites every haplotype carries (a window's constant `add`), and of the kept columns' weights
+    std::vector<uint64_t> ones_wt_prefix, kept_wt_prefix;
     std::vector<uint64_t> wt_prefix;  // weighted: prefix sums of the (ORIGINAL, if compacted) site weights, n + 1 entries
     int device = 0;
     mutable int users = 0;      // live scan plans referencing this matrix (impop_matrix_free refuses while > 0)

@@ -514,9 +514,9 @@ IMPOP_API int impop_matrix_compact(impop_ctx *ctx, const impop_matrix *in, impop
     uint32_t *d_cnt = (uint32_t *)((char *)d + o_cnt);
     uint64_t n_kept = 0;
     // a source that kept its hap-major copy hands the all-pairs path on: the compacted matrix gets its own RB32
-    // operand and the bitmap of the dropped all-ones sites (not for weighted sources: their dropped columns would
-    // each add their own weight)
-    const bool want_pairs = in->d_rb != nullptr && in->wt_prefix.empty();
+    // operand and the bitmap of the dropped all-ones sites (their count — for a weighted source the sum of their
+    // weights, from host prefix sums built below — comes back as a per-window constant)
+    const bool want_pairs = in->d_rb != nullptr;
     uint64_t *d_ones = nullptr;
     if (want_pairs && nb) HIP_TRY(hipMalloc((void **)&d_ones, nb * 8 + 256));
     if (nb) {
@@ -579,6 +579,25 @@ IMPOP_API int impop_matrix_compact(impop_ctx *ctx, const impop_matrix *in, impop
             if ((e = hipMalloc((void **)&m->d_wt, n_kept * 4ull)) != hipSuccess) return fail(hip_fail(e, "hipMalloc(weights)", __FILE__, __LINE__));
             if ((e = hipMemcpy(m->d_wt, kept.data(), n_kept * 4ull, hipMemcpyHostToDevice)) != hipSuccess)
                 return fail(hip_fail(e, "hipMemcpy(weights)", __FILE__, __LINE__));
+            if (want_pairs) {
+                m->kept_wt_prefix.resize(n_kept + 1);
+                m->kept_wt_prefix[0] = 0;
+                for (uint64_t k = 0; k < n_kept; ++k) m->kept_wt_prefix[k + 1] = m->kept_wt_prefix[k] + kept[k];
+            }
+        }
+        if (want_pairs && m->kept_wt_prefix.empty()) m->kept_wt_prefix.assign(1, 0);  // nothing kept
+        if (want_pairs) {  // weights of the dropped all-ones sites, as prefix sums over the original coordinates
+            std::vector<uint64_t> ones(nb);
+            hipError_t e;
+            if (nb && (e = hipMemcpy(ones.data(), d_ones, nb * 8, hipMemcpyDeviceToHost)) != hipSuccess)
+                return fail(hip_fail(e, "hipMemcpy(all-ones bitmap)", __FILE__, __LINE__));
+            m->ones_wt_prefix.resize(g.n_site + 1);
+            uint64_t acc = 0;
+            for (uint64_t i = 0; i < g.n_site; ++i) {
+                m->ones_wt_prefix[i] = acc;
+                if ((ones[i >> 6] >> (i & 63)) & 1ull) acc += in->wt_prefix[i + 1] - in->wt_prefix[i];
+            }
+            m->ones_wt_prefix[g.n_site] = acc;
         }
     }
     *out = m;

@@ -727,6 +727,11 @@ __global__ void gram_accumulate_kernel(int32_t *__restrict__ acc, const int32_t 
 static int ensure_weight_planes(impop_ctx *ctx, const impop_matrix *m) {
     if (m->d_wplanes) return IMPOP_OK;
     const uint64_t n_dword = 2 * m->g.n_block;
+    if (n_dword == 0) {  // no column at all (a weighted matrix compacted to nothing): no plane has a bit
+        m->wplane_bits = 0;
+        m->wplane_stride = 0;
+        return IMPOP_OK;
+    }
     uint32_t *d_used = nullptr;
     HIP_TRY(hipMalloc((void **)&m->d_wplanes, 32ull * n_dword * 4 + 256));
     d_used = m->d_wplanes + 32ull * n_dword;
@@ -758,9 +763,10 @@ static int launch_gram_any(impop_ctx *ctx, const impop_matrix *m, const GramWind
         }
     const uint64_t count = (uint64_t)n_win * m->n_hap_pad * m->n_hap_pad;
     uint64_t heaviest = 0;
+    const std::vector<uint64_t> &pre = m->compact ? m->kept_wt_prefix : m->wt_prefix;  // the cells are in MATRIX coordinates
     for (uint32_t i = 0; i < n_win; ++i)
         if (h_wins[i].site_end > h_wins[i].site_begin)
-            heaviest = std::max(heaviest, m->wt_prefix[h_wins[i].site_end] - m->wt_prefix[h_wins[i].site_begin]);
+            heaviest = std::max(heaviest, pre[h_wins[i].site_end] - pre[h_wins[i].site_begin]);
     if (gram_planes_in_task() && m->wplane_bits && heaviest < GRAM_FUSED_WEIGHT_LIMIT)
         return launch_gram(ctx, m, m->d_rb, d_wins, n_win, d_out, max_window_sites, -1, true);
     REQUIRE(d_tmp || !m->wplane_bits, "weighted Gram: no buffer for the plane partials");
@@ -862,6 +868,12 @@ static inline uint64_t window_W(const impop_matrix *m, uint64_t s0, uint64_t s1)
     return m->wt_prefix.empty() ? s1 - s0 : m->wt_prefix[s1] - m->wt_prefix[s0];
 }
 
+// compacted from a weighted matrix: the summed weights of the dropped all-ones sites of [s0, s1) (original coordinates)
+static inline uint32_t ones_weight(const impop_matrix *m, uint64_t s0, uint64_t s1) {
+    return (uint32_t)(m->ones_wt_prefix[s1] - m->ones_wt_prefix[s0]);  // < 2^31: part of the window's W
+}
+static inline bool compact_weighted(const impop_matrix *m) { return m->compact && !m->ones_wt_prefix.empty(); }
+
 struct Carve2 {
     char *base;
     size_t off = 0;
@@ -882,8 +894,7 @@ using namespace impop;
 static int check_pairwise_args(impop_ctx *ctx, const impop_matrix *m, uint64_t s0, uint64_t s1, const char *fn) {
     REQUIRE(ctx && m, "%s: NULL argument", fn);
     if (m->compact && !(m->d_rb && m->d_onesmap)) {
-        set_error("%s: this compacted matrix has no all-pairs operand (compact a matrix that kept IMPOP_KEEP_HAP_MAJOR and has no "
-                  "site weights)", fn);
+        set_error("%s: this compacted matrix has no all-pairs operand (compact a matrix that kept IMPOP_KEEP_HAP_MAJOR)", fn);
         return IMPOP_E_UNSUPPORTED;
     }
     REQUIRE(m->d_rb, "%s: matrix was created without IMPOP_KEEP_HAP_MAJOR", fn);
@@ -915,9 +926,14 @@ IMPOP_API int impop_pairwise_counts(impop_ctx *ctx, const impop_matrix *m, uint6
     rc = launch_gram_any(ctx, m, d_w, &w, 1, d_g, d_t, w.site_end - w.site_begin);
     if (rc) return rc;
     const GramWindow ow{site_begin, site_end};
-    if (m->compact) {  // + the dropped sites every haplotype carries
-        HIP_TRY(hipMemcpyAsync(d_ow, &ow, sizeof ow, hipMemcpyHostToDevice, ctx->stream));
-        hipLaunchKernelGGL(seg_count_kernel, dim3(1), dim3(256), 0, ctx->stream, m->d_onesmap, d_ow, 1, (impop_window_stats *)nullptr, d_add);
+    const uint32_t add_w = compact_weighted(m) ? ones_weight(m, site_begin, site_end) : 0u;
+    if (m->compact) {  // + the dropped sites every haplotype carries (their count, or their summed weights)
+        if (compact_weighted(m)) {
+            HIP_TRY(hipMemcpyAsync(d_add, &add_w, 4, hipMemcpyHostToDevice, ctx->stream));
+        } else {
+            HIP_TRY(hipMemcpyAsync(d_ow, &ow, sizeof ow, hipMemcpyHostToDevice, ctx->stream));
+            hipLaunchKernelGGL(seg_count_kernel, dim3(1), dim3(256), 0, ctx->stream, m->d_onesmap, d_ow, 1, (impop_window_stats *)nullptr, d_add);
+        }
         hipLaunchKernelGGL(gram_add_const_kernel, dim3((n + 15) / 16, (n + 15) / 16), dim3(16, 16), 0, ctx->stream, d_g, ld, n, d_add);
         HIP_TRY(hipGetLastError());
     }
@@ -959,10 +975,15 @@ IMPOP_API int impop_pairwise_identity(impop_ctx *ctx, const impop_matrix *m, uin
     SimBatch b{};
     b.gram = d_g; b.stride = (uint64_t)ld * ld; b.ld = ld; b.n = n; b.W = d_W; b.kind = identity_kind; b.round_digits = -1;
     const GramWindow ow{site_begin, site_end};
+    const uint32_t add_w = compact_weighted(m) ? ones_weight(m, site_begin, site_end) : 0u;
     if (m->compact) {
-        HIP_TRY(hipMemcpyAsync(d_ow, &ow, sizeof ow, hipMemcpyHostToDevice, ctx->stream));
-        hipLaunchKernelGGL(seg_count_kernel, dim3(1), dim3(256), 0, ctx->stream, m->d_onesmap, d_ow, 1, (impop_window_stats *)nullptr, d_add);
-        HIP_TRY(hipGetLastError());
+        if (compact_weighted(m)) {
+            HIP_TRY(hipMemcpyAsync(d_add, &add_w, 4, hipMemcpyHostToDevice, ctx->stream));
+        } else {
+            HIP_TRY(hipMemcpyAsync(d_ow, &ow, sizeof ow, hipMemcpyHostToDevice, ctx->stream));
+            hipLaunchKernelGGL(seg_count_kernel, dim3(1), dim3(256), 0, ctx->stream, m->d_onesmap, d_ow, 1, (impop_window_stats *)nullptr, d_add);
+            HIP_TRY(hipGetLastError());
+        }
         b.add = d_add;
     }
     hipLaunchKernelGGL(identity_dense_kernel, dim3((n + 15) / 16, (n + 15) / 16), dim3(16, 16), 0, ctx->stream, b, n, d_id);
@@ -1177,6 +1198,7 @@ IMPOP_API int impop_pairwise_scan(impop_ctx *ctx, const impop_matrix *m, const i
     uint32_t *fv = reinterpret_cast<uint32_t *>(hmeta.data() + o_first), *cvv = reinterpret_cast<uint32_t *>(hmeta.data() + o_count);
     impop_window_stats *sv = reinterpret_cast<impop_window_stats *>(hmeta.data() + o_s);
     std::vector<impop_pairwise_stats> ov(cap);
+    std::vector<uint32_t> add_h;
     for (uint64_t base = 0; base < n_windows;) {
         // windows ord[base .. base+cnt): their cells are [c_lo, c_hi)
         uint64_t cnt = 0;
@@ -1229,7 +1251,12 @@ IMPOP_API int impop_pairwise_scan(impop_ctx *ctx, const impop_matrix *m, const i
         b.gram = d_g; b.stride = (uint64_t)ld * ld; b.ld = ld; b.n = n; b.W = d_W; b.kind = params->identity_kind;
         b.round_digits = params->round_digits < 0 ? -1 : params->round_digits;
         b.seg_first = d_first; b.seg_count = d_count;
-        if (m->compact) {
+        if (compact_weighted(m)) {  // the dropped all-ones sites' summed weights, from the host prefix sums
+            add_h.resize(cnt);
+            for (uint64_t k = 0; k < cnt; ++k) add_h[k] = ones_weight(m, windows[ord[base + k]].site_begin, windows[ord[base + k]].site_end);
+            PW_TRY(hipMemcpyAsync(d_add, add_h.data(), cnt * 4, hipMemcpyHostToDevice, ctx->stream));
+            b.add = d_add;
+        } else if (m->compact) {    // ... their count, from the bitmap on the device
             hipLaunchKernelGGL(seg_count_kernel, dim3((uint32_t)((cnt + 3) / 4)), dim3(256), 0, ctx->stream, m->d_onesmap, d_ow, cnt,
                                (impop_window_stats *)nullptr, d_add);
             PW_TRY(hipGetLastError());

@@ -112,11 +112,13 @@ int impop_matrix_set_site_weights(impop_ctx *ctx, impop_matrix *m, const uint32_
  * (what `povu gfa2vcf | wc -l` counts, run_tajd.sh:148), so impop_scan / impop_scan_plan_* /
  * impop_scan_multi on the compacted matrix, given windows in the ORIGINAL site coordinates, return
  * records identical to those of the full matrix (n_sites = the window's original length) while
- * streaming only the variable sites.  When `m` kept its hap-major copy (IMPOP_KEEP_HAP_MAJOR) and has no site weights,
- * the compacted matrix serves the all-pairs path too: a dropped site that NO haplotype carries adds nothing to any
- * I_ij, one that EVERY haplotype carries adds exactly 1 to every I_ij (diagonal included), so impop_pairwise_* contract
- * the kept sites of a window only and add the window's count of dropped all-ones sites (kept as a bitmap in
- * original coordinates) — identical counts, identities and records from W/S times fewer multiply-adds.
+ * streaming only the variable sites.  When `m` kept its hap-major copy (IMPOP_KEEP_HAP_MAJOR), the compacted matrix
+ * serves the all-pairs path too: a dropped site that NO haplotype carries adds nothing to any I_ij, one that EVERY
+ * haplotype carries adds exactly 1 — its weight w_s on a weighted matrix — to every I_ij (diagonal included), so
+ * impop_pairwise_* contract the kept sites of a window only and add the window's count of dropped all-ones sites (a
+ * bitmap in original coordinates; for a weighted source, host prefix sums of their weights) — identical counts,
+ * identities and records from W/S times fewer multiply-adds, and on node-level matrices without the long shared
+ * anchors' weight planes.
  * Per-site outputs (impop_afs, impop_site_counts, impop_ehh) return IMPOP_E_UNSUPPORTED on a compacted matrix. */
 int impop_matrix_compact(impop_ctx *ctx, const impop_matrix *m, impop_matrix **out);
 /* original site index of kept sites [first, first+count) of a compacted matrix; n_site_orig (nullable)

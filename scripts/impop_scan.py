@@ -147,10 +147,6 @@ def main():
         if mf.site_weight is not None:
             bm.set_site_weights(mf.site_weight)
     if args.compact:
-        if need_pairwise and mf.site_weight is not None:
-            print("Error: --compact on a weighted (node-level) matrix cannot serve the all-pairs path (thresholded / rounded "
-                  "pica2, grouped Fst)", file=sys.stderr)
-            sys.exit(2)
         full = bm
         bm = full.compact()
         full.free()

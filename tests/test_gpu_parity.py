@@ -1317,6 +1317,48 @@ def test_all_pairs_path_on_compacted_matrix(ctx, oracle):
                 ref = full.pairwise_scan(wins, mp, inA, inB, kind=kind, threshold=thr, round_digits=rd, fst_method=meth)
                 assert got.tobytes() == ref.tobytes(), (n, kind, thr, rd, meth)
         cm.free(); full.free()
+    # weighted source (one column per graph node, node lengths as weights): the dropped all-ones columns come back as the
+    # SUM OF THEIR WEIGHTS on every I_ij (long shared anchors leave the contraction, and with them the high weight planes)
+    n, W = 120, 6000
+    anc = (rng.random(W) < 0.5).astype(np.uint8)
+    f = np.repeat(anc[None], 5, axis=0) ^ (rng.random((5, W)) < 0.01).astype(np.uint8)
+    m = f[rng.integers(0, 5, size=n)] ^ (rng.random((n, W)) < 0.001).astype(np.uint8)
+    w = rng.integers(1, 8, size=W).astype(np.uint32)
+    c = m.sum(axis=0)
+    w[c == n] = rng.integers(100, 3000, size=int((c == n).sum())).astype(np.uint32)   # anchors: long, carried by everybody
+    full = ctx.upload_dense(m, keep_hap_major=True)
+    full.set_site_weights(w)
+    cm = full.compact()
+    assert cm.n_site == int(((c > 0) & (c < n)).sum())
+    cum = np.concatenate(([0], np.cumsum(w.astype(np.int64))))
+    mi = m.astype(np.int64)
+    for a, b in ((0, W), (17, W - 33), (3000, 3001), (W - 64, W)):
+        I = cm.pairwise_counts(a, b)
+        assert (I.astype(np.int64) == (mi[:, a:b] * w[a:b].astype(np.int64)) @ mi[:, a:b].T).all(), (a, b)
+        assert (I == full.pairwise_counts(a, b)).all()
+        for kind in ("match", "dice"):
+            assert cm.pairwise_identity(a, b, kind).tobytes() == full.pairwise_identity(a, b, kind).tobytes()
+    inA = (rng.random(n) < 0.4).astype(np.uint8); inB = (rng.random(n) < 0.4).astype(np.uint8)
+    inP = (rng.random(n) < 0.8).astype(np.uint8)
+    for spans in ([(k, min(k + 400, W)) for k in range(0, W, 400)], [(k, min(k + 600, W)) for k in range(0, W - 200, 200)]):
+        wins = [(a, b, int(cum[b] - cum[a])) for a, b in spans]
+        for kind, thr, rd, meth, mp in (("match", 0.999, 5, "direct", None), ("dice", 0.9995, None, "direct", inP),
+                                        ("match", 0.998, 4, "grouped", None)):
+            got = cm.pairwise_scan(wins, mp, inA, inB, kind=kind, threshold=thr, round_digits=rd, fst_method=meth)
+            ref = full.pairwise_scan(wins, mp, inA, inB, kind=kind, threshold=thr, round_digits=rd, fst_method=meth)
+            assert got.tobytes() == ref.tobytes(), (kind, thr, rd, meth)
+    cm.free(); full.free()
+    # nothing variable at all: the compaction keeps no column, every I_ij is the constant
+    mono = np.zeros((20, 300), np.uint8); mono[:, ::3] = 1
+    wm = rng.integers(1, 500, size=300).astype(np.uint32)
+    full = ctx.upload_dense(mono, keep_hap_major=True)
+    full.set_site_weights(wm)
+    cm = full.compact()
+    assert cm.n_site == 0
+    assert (cm.pairwise_counts(10, 200) == int(wm[10:200][mono[0, 10:200] == 1].sum())).all()
+    w1 = [(0, 300, int(wm.sum())), (10, 200, int(wm[10:200].sum()))]
+    assert cm.pairwise_scan(w1, None, None, None).tobytes() == full.pairwise_scan(w1, None, None, None).tobytes()
+    cm.free(); full.free()
     # a compacted matrix without the operand (source kept no hap-major copy) still refuses, loudly
     src = ctx.upload_dense(m, keep_hap_major=False)
     c2 = src.compact()

@@ -61,6 +61,9 @@ while time.time() < t_end:
         gw = bm.pairwise_scan(wins, inP, inA, inB, kind=kind, threshold=thr, round_digits=rd, fst_method=meth, s_scope=2)
         ge = be.pairwise_scan(we, inP, inA, inB, kind=kind, threshold=thr, round_digits=rd, fst_method=meth, s_scope=2)
         assert gw.tobytes() == ge.tobytes(), (n, W, "weighted")
+        cw = bm.compact()  # weighted source: dropped all-ones columns come back as their summed weights
+        assert cw.pairwise_scan(wins, inP, inA, inB, kind=kind, threshold=thr, round_digits=rd, fst_method=meth, s_scope=2).tobytes() == gw.tobytes(), (n, W, "weighted compact")
+        cw.free()
         be.free()
         bm.set_site_weights(None)
     if n <= 200 and wins:

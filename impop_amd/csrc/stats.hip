@@ -235,6 +235,7 @@ __device__ inline uint32_t greedy_groups_bits(const uint64_t *__restrict__ adj, 
     constexpr uint32_t ROWS_S = GG_ROWS;
     __shared__ uint32_t cand[64];
     __shared__ uint32_t sh_n, sh_G;
+    __shared__ uint64_t ufree[128];  // wave 0's free set, published for its own per-candidate look-ups
     if (m == 0) return 0;
     const uint32_t tid = threadIdx.x, lane = tid & 63;
     const uint32_t aw = bit_words(m), nh = aw / 4;
@@ -259,7 +260,8 @@ __device__ inline uint32_t greedy_groups_bits(const uint64_t *__restrict__ adj, 
     uint64_t u0 = initial(lane), u1 = initial(lane + 64);  // the free set (wave 0's copy is the one that counts)
     uint32_t G = 0, h_first = 0;
     __syncthreads();
-    for (;;) {
+    // every block resolves at least one candidate: m blocks bound the loop whatever happens (a grid must drain)
+    for (uint32_t guard = 0; guard <= m; ++guard) {
         uint32_t mycand = 0;  // wave 0: lane b holds candidate b
         if (tid < 64) {  // the next up-to-B free positions, ascending: uniform work on words read across the lanes
             // the serial stretches of one wave: ahead of the other problems' waves on this SIMD while they last
@@ -339,27 +341,60 @@ __device__ inline uint32_t greedy_groups_bits(const uint64_t *__restrict__ adj, 
         __syncthreads();
         if (tid < 64) {
             __builtin_amdgcn_s_setprio(3);
-            // rows do not depend on the state of the grouping: the next candidate's words are read while this one is resolved
-            uint64_t r0 = lane < aw ? rows[lane] : 0, r1 = lane + 64 < aw ? rows[lane + 64] : 0;
-            for (uint32_t b = 0; b < n; ++b) {
-                const uint64_t c0 = r0, c1 = r1;
-                if (b + 1 < n) {
-                    r0 = lane < aw ? rows[(uint64_t)(b + 1) * aw + lane] : 0;
-                    r1 = lane + 64 < aw ? rows[(uint64_t)(b + 1) * aw + lane + 64] : 0;
+            // Lane b looks at candidate b: is it still free, and does its row meet the free set at all?  Candidates that are
+            // free and whose rows are empty — up to the first candidate with a non-empty row — cannot be absorbed by anybody
+            // in between and absorb nobody: they become singleton groups TOGETHER (ranks from a ballot).  Then the first
+            // non-empty candidate is resolved the reference's way, the flags are taken again (the free set changed), and so
+            // on.  With hundreds of groups per window most candidates are such singletons: one pass instead of a dependent
+            // chain of LDS reads, lane reads and bit loops per candidate.
+            // `ufree` carries the free set from the lanes that hold it to the lanes that look candidates up: lanes of one
+            // wave talking through LDS, so volatile — to the compiler a lane's plain LDS traffic is private, and it forwarded
+            // a lane's own earlier store over what other lanes had written since (first version: groups counted twice).
+            volatile uint64_t *uf = ufree;
+            uint32_t pos = 0;
+            while (pos < n) {
+                uf[lane] = u0; uf[lane + 64] = u1;
+                bool alive = false, nonempty = false;
+                const uint32_t c = mycand;
+                if (lane >= pos && lane < n) {
+                    alive = (uf[bit_word(c)] >> bit_lane(c)) & 1;
+                    if (alive)
+                        for (uint32_t w = 4 * (c >> 8); w < aw; ++w)
+                            if (rows[(uint64_t)lane * aw + w] & uf[w]) { nonempty = true; break; }
                 }
-                const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)mycand, (int)b);
-                const uint32_t cw = bit_word(c), cl = bit_lane(c), hl = cw & 63;
-                const uint64_t holder = readlane_u64(cw < 64 ? u0 : u1, hl);
-                if (!((holder >> cl) & 1)) continue;  // absorbed by an earlier seed of this block (uniform)
-                uint64_t n0 = c0 & u0, n1 = c1 & u1;
-                if (lane == hl) { if (cw < 64) n0 |= 1ull << cl; else n1 |= 1ull << cl; }  // the seed itself
-                u0 &= ~n0; u1 &= ~n1;
-                const uint32_t cnt = (uint32_t)__popcll(n0) + (uint32_t)__popcll(n1);
-                if (cnt) atomicAdd(&gsz[G], cnt);
-                while (n0) { grp[bit_pos(lane, (uint32_t)__ffsll((unsigned long long)n0) - 1)] = G; n0 &= n0 - 1; }
-                while (n1) { grp[bit_pos(lane + 64, (uint32_t)__ffsll((unsigned long long)n1) - 1)] = G; n1 &= n1 - 1; }
-                if (lane == 0 && rep) rep[G] = c;
-                ++G;
+                const uint64_t bal_alive = __ballot(alive), bal_busy = __ballot(nonempty);
+                const uint32_t first = bal_busy ? (uint32_t)__ffsll((unsigned long long)bal_busy) - 1 : n;  // >= pos
+                uint64_t lone = bal_alive & (first >= 64 ? ~0ull : ((1ull << first) - 1));                // free, row empty, before `first`
+                if ((lone >> lane) & 1) {
+                    const uint32_t gid = G + (uint32_t)__popcll(lone & ((1ull << lane) - 1));
+                    grp[c] = gid;
+                    gsz[gid] = 1;
+                    if (rep) rep[gid] = c;
+                }
+                G += (uint32_t)__popcll(lone);
+                while (lone) {  // their bits leave the free set: uniform walk, the holder lane clears
+                    const uint32_t bsel = (uint32_t)__ffsll((unsigned long long)lone) - 1;
+                    lone &= lone - 1;
+                    const uint32_t cs = (uint32_t)__builtin_amdgcn_readlane((int)mycand, (int)bsel);
+                    const uint32_t sw = bit_word(cs);
+                    if (lane == (sw & 63)) { if (sw < 64) u0 &= ~(1ull << bit_lane(cs)); else u1 &= ~(1ull << bit_lane(cs)); }
+                }
+                if (first >= n) break;
+                {   // candidate `first`: free, and its row takes free elements with it (pica2.py:100-108)
+                    const uint32_t cf = (uint32_t)__builtin_amdgcn_readlane((int)mycand, (int)first);
+                    const uint32_t cw = bit_word(cf), cl = bit_lane(cf), hl = cw & 63;
+                    uint64_t n0 = (lane < aw ? rows[(uint64_t)first * aw + lane] : 0) & u0;
+                    uint64_t n1 = (lane + 64 < aw ? rows[(uint64_t)first * aw + lane + 64] : 0) & u1;
+                    if (lane == hl) { if (cw < 64) n0 |= 1ull << cl; else n1 |= 1ull << cl; }  // the seed itself
+                    u0 &= ~n0; u1 &= ~n1;
+                    const uint32_t cnt = (uint32_t)__popcll(n0) + (uint32_t)__popcll(n1);
+                    if (cnt) atomicAdd(&gsz[G], cnt);
+                    while (n0) { grp[bit_pos(lane, (uint32_t)__ffsll((unsigned long long)n0) - 1)] = G; n0 &= n0 - 1; }
+                    while (n1) { grp[bit_pos(lane + 64, (uint32_t)__ffsll((unsigned long long)n1) - 1)] = G; n1 &= n1 - 1; }
+                    if (lane == 0 && rep) rep[G] = cf;
+                    ++G;
+                }
+                pos = first + 1;
             }
             if (lane == 0) sh_G = G;
             __builtin_amdgcn_s_setprio(0);

@@ -52,8 +52,8 @@ __global__ __launch_bounds__(256) void hm_to_sb_kernel(const uint32_t *__restric
 }
 
 // ---- SB64 -> hap-major ---------------------------------------------------------------
-// One wave per block; lane = site.  __ballot of bit j of the site's dword k is exactly
-// the 64-site hap-major word of haplotype 32k+j.
+// One wave per block; lane = site.  The 64-site hap-major word of haplotype 32k+j is bit j of every site's dword k,
+// gathered by transposing the two 32 x 32 bit matrices a dword k forms over the wave's halves (below).
 __global__ __launch_bounds__(256) void sb_to_hm_kernel(const uint32_t *__restrict__ sb, uint32_t wps, uint32_t G,
                                                        uint32_t r, uint64_t blk_begin, uint64_t blk_end,
                                                        uint32_t *__restrict__ hm, uint64_t hm_stride,
@@ -64,8 +64,8 @@ __global__ __launch_bounds__(256) void sb_to_hm_kernel(const uint32_t *__restric
     // Dword k of site `lane` holds haplotypes 32k .. 32k+31: each half of the wave is a 32 x 32 bit matrix (site x haplotype)
     // to transpose.  Five rounds of swapping the off-diagonal s x s blocks of every 2s x 2s block with lane ^ s (s = 16 .. 1):
     // one cross-lane move + four bit operations per round, against 32 ballots per dword before (18.8 ms per 12 GB matrix;
-    // 10.8 ms with the butterfly and whole-granule loads).  Afterwards lane j of half h holds, for haplotype 32k + j, the sites 32h .. 32h+31 of
-    // the block: dword h of that row's pair.
+    // 10.8 ms with the butterfly and whole-granule loads).  Afterwards lane j of half h holds, for haplotype 32k + j, the
+    // sites 32h .. 32h+31 of the block: dword h of that row's pair.
     const uint32_t half = lane >> 5, j = lane & 31;
     const uint32_t *blk = sb + b * 64ull * wps;
     uint4 q = {0u, 0u, 0u, 0u};  // the granule dword k comes out of

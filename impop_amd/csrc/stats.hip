@@ -570,6 +570,44 @@ __global__ __launch_bounds__(ST, 5) void pica2_kernel(SimBatch batch, const uint
         // (a thread per row read one cache line per lane and pair: 4096 singleton groups cost 94 ms per window) —
         // lane partials in j order, fixed butterfly across lanes
         const uint32_t lane = tid & 63;
+        // Gram problems of up to 512 elements, rows = positions: the row of a representative is walked over ALL positions
+        // right of it with one 16-byte load per lane and 256 positions (as hfst_kernel does), against a per-POSITION
+        // frequency table — f of the group a position represents, 0 for every other position, whose term then vanishes —
+        // instead of one scalar Gram load per representative pair.  Every pair is present on a Gram problem, so the pair
+        // count is G(G-1)/2.
+        const bool quads = S.gram && S.diag && !idx && n_el <= GG_ROWS && (S.ld & 3u) == 0 && (S.seg_stride & 3ull) == 0 &&
+                           ((uintptr_t)S.gram & 15) == 0;
+        if (quads) {
+            double *fpos = reinterpret_cast<double *>(rows_s);
+            for (uint32_t o = tid; o < GG_ROWS; o += ST) fpos[o] = 0.0;
+            __syncthreads();
+            for (uint32_t g = tid; g < G; g += ST) fpos[rep[g]] = (double)gsz[g] / total;
+            __syncthreads();
+            for (uint32_t i = tid >> 6; i < G; i += ST / 64) {
+                const uint32_t rr = rep[i];
+                const double fi = (double)gsz[i] / total;
+                const int64_t ar = S.diag[rr];
+                double acc = 0.0;
+                for (uint32_t o4 = 256 * (rr >> 8) + 4 * lane; o4 < n_el; o4 += 256) {
+                    if (o4 + 3 <= rr) continue;  // entirely left of the diagonal
+                    const int32_t *gp = S.gram + (uint64_t)rr * S.ld + o4;  // o4 + 3 < ld: ld is a multiple of 4, o4 < n_el <= ld
+                    i32q v = *reinterpret_cast<const i32q *>(gp);
+                    for (uint32_t k = 1; k < S.nseg; ++k) v += *reinterpret_cast<const i32q *>(gp + k * S.seg_stride);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const uint32_t o = o4 + e;
+                        const bool live = o > rr && o < n_el;
+                        // dead positions get the all-zero pair (a memo hit, never the division path) and frequency 0
+                        const double sv = sim_from_gram(S, live ? (int64_t)v[e] + S.add : 0, live ? ar : 0, live ? (int64_t)S.diag[live ? o : rr] : 0);
+                        const double fj = live ? fpos[o] : 0.0;
+                        acc += 2 * ((1 - sv) * fi * fj);
+                    }
+                }
+                acc = wave_sum_f64(acc);
+                if (lane == 0) rowsum[i] = acc;
+            }
+            if (tid == 0 && G > 1) { have = 1; npairs = (uint64_t)G * (G - 1) / 2; }
+        } else {
         // f_g = size / total once per group instead of a double-precision division per PAIR (the same quotient); the
         // table takes the candidate-row words of Step 1.  (Fewer instructions, no measurable change at 465 groups per
         // window: 4.9 ms per 4096 windows either way — the rows' Gram loads bound this loop, not its arithmetic.)
@@ -603,6 +641,7 @@ __global__ __launch_bounds__(ST, 5) void pica2_kernel(SimBatch batch, const uint
             }
             acc = wave_sum_f64(acc);
             if (lane == 0) rowsum[i] = acc;
+        }
         }
     }
     if (have) atomicOr(&sh_have, 1u);

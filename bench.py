@@ -66,60 +66,113 @@ def host_cores():
     return max(min(n, 16), 1)
 
 
-def secondary_points(ctx, bm, windows, in_a, in_b, ref_records):
-    """Secondary measurements reported NEXT TO the headline (never folded into `value`): SURVEY §8(d)'s
-    "W = S-only" point (the same windows scanned from the matrix compacted to its variable sites, records
-    byte-identical) and the all-pairs (Gram, MFMA-bound) mode of the same window shape."""
-    import numpy as np
+FP4_DENSE_PEAK_TFLOPS = 10000.0  # MI355X FP4 / FP6 dense MFMA peak (MI355X_MICROARCH.md: ~10 PF dense); 1 MAC = 2 FLOP
 
+
+def all_pairs_point(ctx, n, W, in_a, in_b, n_windows=4096):
+    """The all-pairs (Gram) mode at the reference's DEFAULT settings — run_tajd.sh:9-10,166-180: pica2 -t 0.999 -r 5 per window,
+    its "%.8f" pi into Tajima's D; h-fst on the same identities — on the headline window shape (n haplotypes x W sites).
+    This path is MFMA-bound: one impop_pairwise_scan call over `n_windows` resident windows, host clock around the
+    whole call (launches, epilogue kernels, copies of the 96-byte records included).  Reported NEXT TO the headline under
+    `secondary.all_pairs_mode`, with its own roofline block; never folded into `value`."""
     import impop_amd
+    t0 = time.perf_counter()
+    pm = ctx.synthetic(n, W * n_windows, seed=20251031, keep_hap_major=True)
+    ctx.synchronize()
+    t_gen = time.perf_counter() - t0
+    pw = impop_amd.fixed_windows(W * n_windows, W)
+    kw = dict(kind="match", threshold=0.999, round_digits=5)
+    pm.pairwise_scan(pw[:64], None, in_a, in_b, **kw)  # scratch, code objects, the matrix's site bitmap
+    first = pm.pairwise_scan(pw, None, in_a, in_b, **kw)
+    ctx.synchronize()
+    reps = 3
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        res = pm.pairwise_scan(pw, None, in_a, in_b, **kw)
+    dt = (time.perf_counter() - t0) / reps
+    assert res.tobytes() == first.tobytes()  # integer Gram + ordered fp64 epilogues: byte-reproducible
+    # parity gate of this mode: two windows against the CPU oracle's dense restatement of the same chain
+    import numpy as np
+    from oracle import oracle as orc
+    orc.build()
+    ones = orc.pack_mask(np.ones(n, np.uint8))
+    for wi in (0, n_windows - 1):
+        s0, s1 = int(pw[wi]["site_begin"]), int(pw[wi]["site_end"])
+        bits = pm.download(s0, s1)
+        sim = orc.identity(orc.pairwise_counts(bits, n, 0, s1 - s0), s1 - s0, 0)
+        pi, ps, _, G = orc.pica2(sim, 0.999, W, 5)
+        S = orc.window_sitecount(bits, n, 0, s1 - s0, ones, orc.pack_mask(in_a), orc.pack_mask(in_b), W)["s_all"]
+        D = orc.tajimas_d(n, float(S), orc.py_round(ps, 8))[0]
+        h, _ = orc.hfst(sim, in_a, in_b, W, 5)
+        got = res[wi]
+        assert int(got["n_groups"]) == G and int(got["s_all"]) == S, ("all-pairs parity gate", wi, int(got["n_groups"]), G)
+        for a_, b_ in ((float(got["pi"]), pi), (float(got["pi_site"]), ps), (float(got["tajima_d"]), D), (float(got["fst"]), h["fst"]),
+                       (float(got["dxy"]), h["dxy"])):
+            assert abs(a_ - b_) <= 1e-9 * max(abs(a_), abs(b_)), ("all-pairs parity gate", wi, a_, b_)
+    macs = n * (n + 1) // 2 * W  # SURVEY §8d: algorithmic MACs per window (upper triangle incl. diagonal)
+    achieved = 2.0 * macs * n_windows / dt / 1e12
+    out = {"windows_per_s": n_windows / dt, "windows": n_windows, "s_per_call": dt, "matrix_generation_s": t_gen,
+           "what": f"impop_pairwise_scan, {n} haplotypes x {W} sites per window: FP4-MFMA Gram + pica2 (-t 0.999 -r 5) + h-fst + S "
+                   "(cached site bitmap) + Tajima's D from the %.8f pi, per window, incl. launches and record copies",
+           "settings": "run_tajd.sh defaults: pica2 -t 0.999 -r 5 -> %.8f -> tj_d",
+           "mean_groups_per_window": float(res["n_groups"].mean()),
+           "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP4_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
+                        "frac": achieved / FP4_DENSE_PEAK_TFLOPS, "traffic": None,
+                        "algorithmic_macs_per_window": macs, "timed": "host clock around the whole call (end to end)",
+                        "kernel": "gram kernel + epilogues"}}
+    return out, pm, pw, res
+
+
+def secondary_points(ctx, bm, windows, in_a, in_b, ref_records, extended, n_pairs_windows=4096):
+    """Secondary measurements reported NEXT TO the headline (never folded into `value`).  Always: the all-pairs (Gram,
+    MFMA-bound) mode at the reference's default settings.  With --secondary also SURVEY §8(d)'s "W = S-only" point (the same
+    windows scanned from the matrix compacted to its variable sites, records byte-identical) and the all-pairs mode on the
+    compacted matrix."""
     out = {}
+    n, W = bm.n_hap, int(windows[0]["site_end"]) - int(windows[0]["site_begin"])
+    pm = None
     try:
-        t0 = time.perf_counter()
-        cm = bm.compact()
-        ctx.synchronize()
-        t_c = time.perf_counter() - t0
-        plan = cm.plan(windows, None, in_a, in_b)
-        plan.launch(); ctx.synchronize()
-        plan.timing(True)
-        for _ in range(20):
-            plan.launch()
-        ms, k = plan.elapsed()
-        same = plan.fetch().tobytes() == ref_records.tobytes()
-        out["variable_sites_only"] = {"windows_per_s_kernel": len(windows) / (ms / k / 1e3), "kernel_ms": ms / k,
-                                      "variable_sites": cm.n_site, "of_sites": bm.n_site, "compaction_s": t_c,
-                                      "layout_GBps": plan.bytes_streamed / (ms / k / 1e3) / 1e9,
-                                      "records_identical_to_full_matrix": bool(same)}
-        plan.destroy(); cm.free()
+        out["all_pairs_mode"], pm, pw, ref_pw = all_pairs_point(ctx, n, W, in_a, in_b, n_pairs_windows)
     except Exception as e:  # a secondary point must not take the headline line down; the error is reported
-        out["variable_sites_only"] = {"error": repr(e)}
-    try:
-        n, W = bm.n_hap, int(windows[0]["site_end"]) - int(windows[0]["site_begin"])
-        NWp = 1024
-        pm = ctx.synthetic(n, W * NWp, seed=20251031, keep_hap_major=True)
-        pw = impop_amd.fixed_windows(W * NWp, W)
-        pm.pairwise_scan(pw[:64], None, in_a, in_b, kind="match", threshold=0.999, round_digits=5)
-        ctx.synchronize()
-        t0 = time.perf_counter()
-        pm.pairwise_scan(pw, None, in_a, in_b, kind="match", threshold=0.999, round_digits=5)
-        dt = time.perf_counter() - t0
-        macs = n * (n + 1) // 2 * W
-        out["all_pairs_mode"] = {"windows_per_s": NWp / dt, "windows": NWp, "what": "FP4-MFMA Gram + pica2 (-t 0.999 -r 5) + h-fst + S "
-                                 "(cached site bitmap) + D per window, incl. copies", "bound": "mfma",
-                                 "algorithmic_macs_per_window": macs, "frac_of_fp4_dense_peak": macs * NWp / dt / 5.0e15}
-        ref_pw = pm.pairwise_scan(pw, None, in_a, in_b, kind="match", threshold=0.999, round_digits=5)
-        cmp_ = pm.compact()  # the all-pairs path on the variable sites only (+ the dropped all-ones count): identical records
-        got_pw = cmp_.pairwise_scan(pw, None, in_a, in_b, kind="match", threshold=0.999, round_digits=5)
-        ctx.synchronize()
-        t0 = time.perf_counter()
-        cmp_.pairwise_scan(pw, None, in_a, in_b, kind="match", threshold=0.999, round_digits=5)
-        dtc = time.perf_counter() - t0
-        out["all_pairs_mode_variable_sites_only"] = {"windows_per_s": NWp / dtc, "windows": NWp, "kept_sites": cmp_.n_site, "of_sites": pm.n_site,
-                                                     "records_identical_to_full_matrix": bool(got_pw.tobytes() == ref_pw.tobytes())}
-        cmp_.free()
-        pm.free()
-    except Exception as e:
         out["all_pairs_mode"] = {"error": repr(e)}
+    if extended and pm is not None:
+        try:
+            kw = dict(kind="match", threshold=0.999, round_digits=5)
+            cmp_ = pm.compact()  # the all-pairs path on the variable sites only (+ the dropped all-ones count): identical records
+            got_pw = cmp_.pairwise_scan(pw, None, in_a, in_b, **kw)
+            ctx.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(3):
+                cmp_.pairwise_scan(pw, None, in_a, in_b, **kw)
+            dtc = (time.perf_counter() - t0) / 3
+            out["all_pairs_mode_variable_sites_only"] = {"windows_per_s": len(pw) / dtc, "windows": len(pw), "kept_sites": cmp_.n_site,
+                                                         "of_sites": pm.n_site,
+                                                         "records_identical_to_full_matrix": bool(got_pw.tobytes() == ref_pw.tobytes())}
+            cmp_.free()
+        except Exception as e:
+            out["all_pairs_mode_variable_sites_only"] = {"error": repr(e)}
+    if pm is not None:
+        pm.free()
+    if extended:
+        try:
+            t0 = time.perf_counter()
+            cm = bm.compact()
+            ctx.synchronize()
+            t_c = time.perf_counter() - t0
+            plan = cm.plan(windows, None, in_a, in_b)
+            plan.launch(); ctx.synchronize()
+            plan.timing(True)
+            for _ in range(20):
+                plan.launch()
+            ms, k = plan.elapsed()
+            same = plan.fetch().tobytes() == ref_records.tobytes()
+            out["variable_sites_only"] = {"windows_per_s_kernel": len(windows) / (ms / k / 1e3), "kernel_ms": ms / k,
+                                          "variable_sites": cm.n_site, "of_sites": bm.n_site, "compaction_s": t_c,
+                                          "layout_GBps": plan.bytes_streamed / (ms / k / 1e3) / 1e9,
+                                          "records_identical_to_full_matrix": bool(same)}
+            plan.destroy(); cm.free()
+        except Exception as e:
+            out["variable_sites_only"] = {"error": repr(e)}
     return out
 
 
@@ -238,9 +291,13 @@ def main():
     ap.add_argument("--tile-blocks", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--secondary", action="store_true",
-                    help="also measure the variable-sites-only scan and the all-pairs mode (reported under `secondary`, never in "
-                         "`value`); off by default so that a rocprofv3 --stats average of the default command is the headline "
-                         "kernel on the headline workload alone")
+                    help="also measure the variable-sites-only scan and the all-pairs mode on the compacted matrix (under "
+                         "`secondary`, never in `value`).  Off by default: the compacted scan launches the headline kernel's own "
+                         "instantiation on another workload, which would pollute a rocprofv3 --stats average of the default command")
+    ap.add_argument("--all-pairs-windows", type=int, default=4096, help="windows of the all-pairs point (one impop_pairwise_scan call)")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the all-pairs point (run_tajd.sh's default chain on the MFMA path) the default command measures "
+                         "after the timed region")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -434,8 +491,8 @@ def main():
     secondary = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu, first = cpu_baseline(bm, windows, in_a, in_b)
-    if rank == 0 and world == 1 and args.secondary:
-        secondary = secondary_points(ctx, bm, windows, in_a, in_b, recs)
+    if rank == 0 and world == 1 and not args.no_secondary:
+        secondary = secondary_points(ctx, bm, windows, in_a, in_b, recs, args.secondary, args.all_pairs_windows)
 
     if rank == 0:
         total_windows = NW * world * args.steps

@@ -122,6 +122,7 @@ def seeded_child(spec_path):
     sc = spec["scripts"]
     pica2 = load("ref_pica2", os.path.join(sc, "pica2.py"))
     hud = load("ref_hud", os.path.join(sc, "hudson", "hud.py"))
+    tjd = load("ref_tj_d", os.path.join(sc, "tj_d.py"))
     names = spec["names"]
     sim = [[float.fromhex(v) for v in row] for row in spec["sim"]]
     n = len(names)
@@ -134,7 +135,11 @@ def seeded_child(spec_path):
         log = io.StringIO()
         pi, ps = pica2.analyze_similarity_matrix(dict(d), elements, len(d), thr, spec["L"], log, rd)
         groups = [ln.strip() for ln in log.getvalue().splitlines() if ln.startswith("  G") and "(size:" in ln]
-        out["pica2"].append({"threshold": float(thr).hex(), "round": rd, "pi": hx(pi), "pi_site": hx(ps), "n_groups": len(groups)})
+        # the rest of run_tajd.sh:166-180: pica2's "%.8f" stdout token -> tj_d.py -p, n = the list's line count, S given
+        pi_text = f"{ps:.8f}"
+        D = tjd.tajimas_d(n, float(spec["S"]), float(pi_text))
+        out["pica2"].append({"threshold": float(thr).hex(), "round": rd, "pi": hx(pi), "pi_site": hx(ps), "n_groups": len(groups),
+                             "pi_text": pi_text, "S": spec["S"], "D": hx(D)})
     A = set()
     for k in spec["insert_order"]:
         if spec["in_a"][k]:
@@ -161,9 +166,10 @@ def seeded_fixture(sc, out_dir, meta):
         return np.array([[1.0 - step * abs(i - j) for j in range(n)] for i in range(n)])
     m, _ = founder_matrix(rng, 36, 900, 5, 0.01, 0.002)
     I = np_counts(m)
-    specs = [("chain5", chain(5, 0.0004), 40, [(0.999, None)], [(0.999, None)]),
-             ("chain12", chain(12, 0.0004), 10, [(0.999, None), (0.9985, 5)], [(0.999, None)]),
-             ("chain31", chain(31, 0.00035), 10, [(0.999, None), (0.999, 3), (0.9975, None)], [(0.999, None), (0.998, 4)]),
+    # (0.999, 5) = the defaults of run_tajd.sh:9-10, last so that the CLI captures (first two cases) stay what they were
+    specs = [("chain5", chain(5, 0.0004), 40, [(0.999, None), (0.999, 5)], [(0.999, None)]),
+             ("chain12", chain(12, 0.0004), 10, [(0.999, None), (0.9985, 5), (0.999, 5)], [(0.999, None)]),
+             ("chain31", chain(31, 0.00035), 10, [(0.999, None), (0.999, 3), (0.9975, None), (0.999, 5)], [(0.999, None), (0.998, 4)]),
              ("founders36_match", np_identity(I, 900, "match"), 10, None, None),
              ("founders36_dice", np_identity(I, 900, "dice"), 10, None, None)]
     for name, sim, n_seeds, pcases, hcases in specs:
@@ -172,7 +178,7 @@ def seeded_fixture(sc, out_dir, meta):
         off = sim[~np.eye(n, dtype=bool)]
         if pcases is None:
             q = [float(np.quantile(off, x)) for x in (0.5, 0.8)]
-            pcases = [(q[0], None), (q[1], None), (q[1], 3)]
+            pcases = [(q[0], None), (q[1], None), (q[1], 3), (q[1], 5)]
             hcases = [(q[0], None), (q[1], 4)]
         pcases = [c for c in pcases if not is_equivalence(sim, c[0], c[1])]
         assert pcases, name
@@ -180,7 +186,7 @@ def seeded_fixture(sc, out_dir, meta):
         in_a = [1 if (i % 3) != 2 and i < (2 * n) // 3 else 0 for i in range(n)]
         in_b = [1 if not in_a[i] else 0 for i in range(n)]
         spec = {"scripts": sc, "names": names, "sim": [[hx(v) for v in row] for row in sim], "insert_order": ins,
-                "pica2_cases": pcases, "hud_cases": hcases, "L": 50000, "in_a": in_a, "in_b": in_b}
+                "pica2_cases": pcases, "hud_cases": hcases, "L": 50000, "in_a": in_a, "in_b": in_b, "S": 3 * n + 7}
         runs = []
         with tempfile.TemporaryDirectory() as td:
             sp = os.path.join(td, "spec.json")
@@ -346,6 +352,9 @@ def main():
         ("n24_w300_clones", 24, 300, 4, 0.05, 0.0, 300),   # exact clones: '>thr' is an equivalence relation
         ("n40_w2000_clones", 40, 2000, 6, 0.01, 0.0, 50000),
         ("n130_w640", 130, 640, 8, 0.02, 0.003, 640),    # >128 haplotypes: second mask word
+        # founders 1-2 % apart, members of a founder a handful of private sites apart: at run_tajd.sh's defaults
+        # (-t 0.999 -r 5) the groups are the founder classes (non-identical members, transitive) — asserted below
+        ("n48_w12000_tight", 48, 12000, 5, 0.01, 0.00015, 12000),
     ]
     for name, n, W, nf, pf, pp, L in specs:
         m, who = founder_matrix(rng, n, W, nf, pf, pp)
@@ -399,6 +408,32 @@ def main():
                 cl = af.cluster(rows, samples, thr)
                 out["af"].append({"threshold": hx(thr), "clusters": [sorted(c) for c in cl]})
             rec["kinds"][kind] = out
+        # The DEFAULT chain of run_tajd.sh (:9-10 THRESHOLD=0.999 R_VALUE=5; :166 pica2.py -t T -l LENGTH -r R; :174 first
+        # stdout token; :180 tj_d.py -n SAMPLE_COUNT -p PI -S S_COUNT), where the grouping does not depend on set order.
+        # "all": every haplotype listed; "subset_a": the sample list = population A (impg similarity --subset-sequence-list,
+        # :160), n = its size, S still from the whole graph (:126,148).
+        rec["tajd_chain_default"] = {}
+        for kind in ("match", "dice"):
+            sim = np_identity(I, W, kind)
+            ent = {}
+            for label, idx in (("all", list(range(n))), ("subset_a", [i for i in range(n) if inA[i]])):
+                sub = sim[np.ix_(idx, idx)]
+                if len(idx) < 2 or not is_equivalence(sub, 0.999, 5):
+                    ent[label] = None
+                    continue
+                nm = [names[i] for i in idx]
+                log = io.StringIO()
+                pi, ps = pica2.analyze_similarity_matrix(sim_dict(sub, nm), set(nm), 0, 0.999, L, log, 5)
+                groups = [ln for ln in log.getvalue().splitlines() if ln.startswith("  G") and "(size:" in ln]
+                pi_text = f"{ps:.8f}"
+                D = tjd.tajimas_d(len(idx), float(rec["S_all"]), float(pi_text))
+                ent[label] = {"threshold": "0.999", "round": 5, "L": L, "n": len(idx), "S": rec["S_all"], "pi": hx(pi), "pi_site": hx(ps),
+                              "pi_text": pi_text, "n_groups": len(groups), "D": hx(D)}
+            rec["tajd_chain_default"][kind] = ent
+        if name == "n48_w12000_tight":
+            for kind in ("match", "dice"):
+                e = rec["tajd_chain_default"][kind]["all"]
+                assert e is not None and 1 < e["n_groups"] < n, (name, kind, e)
         # full chain as wired by run_tajd.sh:166-180 on the `match` identity at t>=1
         sim = np_identity(I, W, "match")
         pi, ps = pica2.analyze_similarity_matrix(sim_dict(sim, names), set(names), 0, 1.0, L, io.StringIO(), None)

@@ -30,7 +30,7 @@ def test_batch_driver_tables(tmp_path, oracle):
     (tmp_path / "all.txt").write_text("\n".join(f"S{i:03d}" for i in range(12)) + "\n")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "impop_scan.py"), "--matrix", str(tmp_path / "m.npz"),
                         "--bed", str(tmp_path / "w.bed"), "--format", "all", "-A", str(tmp_path / "A.txt"), "-B", str(tmp_path / "B.txt"),
-                        "-l", str(tmp_path / "all.txt")], capture_output=True, text=True)
+                        "-l", str(tmp_path / "all.txt"), "-t", "1.0", "-r", "none"], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     lines = r.stdout.strip().split("\n")
     assert lines[0] == "REGION\tLENGTH\tTHRESHOLD\tR_VALUE\tPICA_OUTPUT"       # run_pica2_impg.sh:122
@@ -61,7 +61,7 @@ def test_batch_driver_tables(tmp_path, oracle):
     # haplotype-level list with a repeated line, an unknown name, a comment and a blank: SAMPLES = awk's count (5)
     (tmp_path / "hap.txt").write_text("# panel\nS000_hap1\nS001#2\n\nS001#2\nNOPE_hap1\n  S003_mat\n")
     rh = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "impop_scan.py"), "--matrix", str(tmp_path / "m.npz"),
-                         "--bed", str(tmp_path / "w.bed"), "--format", "tajd", "-l", str(tmp_path / "hap.txt")], capture_output=True, text=True)
+                         "--bed", str(tmp_path / "w.bed"), "--format", "tajd", "-l", str(tmp_path / "hap.txt"), "-t", "1", "-r", "none"], capture_output=True, text=True)
     assert rh.returncode == 0, rh.stderr
     lh = rh.stdout.strip().split("\n")
     sel = np.array([1 if nm.startswith(("S000#1#", "S001#2#", "S003#1#")) else 0 for nm in names], np.uint8)
@@ -75,7 +75,7 @@ def test_batch_driver_tables(tmp_path, oracle):
     # a list whose line count equals the matched haplotypes takes the scan's own D, without a warning
     (tmp_path / "hap3.txt").write_text("S000_hap1\nS001#2\nS003_mat\n")
     r3h = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "impop_scan.py"), "--matrix", str(tmp_path / "m.npz"),
-                          "--bed", str(tmp_path / "w.bed"), "--format", "tajd", "-l", str(tmp_path / "hap3.txt")], capture_output=True, text=True)
+                          "--bed", str(tmp_path / "w.bed"), "--format", "tajd", "-l", str(tmp_path / "hap3.txt"), "-t", "1", "-r", "none"], capture_output=True, text=True)
     assert r3h.returncode == 0 and "sample list has" not in r3h.stderr
     for k, (s0, s1, L, reg) in enumerate(wins):
         w = oracle.window_allpairs(bits, n, s0, s1, oracle.pack_mask(sel), oracle.pack_mask(inA), oracle.pack_mask(inB), L)
@@ -89,7 +89,7 @@ def test_batch_driver_tables(tmp_path, oracle):
     # --compact: the same tables from the matrix compacted to its variable sites
     rc = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "impop_scan.py"), "--matrix", str(tmp_path / "m.npz"),
                          "--bed", str(tmp_path / "w.bed"), "--format", "all", "-A", str(tmp_path / "A.txt"), "-B", str(tmp_path / "B.txt"),
-                         "-l", str(tmp_path / "all.txt"), "--compact"], capture_output=True, text=True)
+                         "-l", str(tmp_path / "all.txt"), "--compact", "-t", "1.0", "-r", "none"], capture_output=True, text=True)
     assert rc.returncode == 0, rc.stderr
     assert rc.stdout == r.stdout
     # 3 x pi table (run_fst_impg.sh): PI_C = pica2 on the union list, here against the oracle's pica2
@@ -108,6 +108,74 @@ def test_batch_driver_tables(tmp_path, oracle):
             assert abs(float(t[col]) - ps) <= 1.0000001e-8, (reg, col, t[col], ps)
         fa, fb, fc = float(t[4]), float(t[5]), float(t[6])
         assert t[7] == f"{0.5 * (fa + fb):.8f}" and t[8] == ("NA" if fc == 0 else f"{(fc - 0.5 * (fa + fb)) / fc:.8f}")
+    # ---- the reference's DEFAULT chain (run_tajd.sh:9-10,166-180): --format tajd without -t / -r is pica2 -t 0.999 -r 5
+    # on the all-pairs path -> "%.8f" -> tj_d with n = the list's line count
+    rd = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "impop_scan.py"), "--matrix", str(tmp_path / "m.npz"),
+                         "--bed", str(tmp_path / "w.bed"), "--format", "tajd", "-l", str(tmp_path / "hap3.txt")], capture_output=True, text=True)
+    assert rd.returncode == 0, rd.stderr
+    ld = rd.stdout.strip().split("\n")
+    assert ld[0] == "REGION\tLENGTH\tSAMPLES\tSEGREGATING_SITES\tPI\tTAJIMAS_D"
+    sel3 = np.array([1 if nm.startswith(("S000#1#", "S001#2#", "S003#1#")) else 0 for nm in names], np.uint8)
+    idx3 = np.nonzero(sel3)[0]
+    for k, (s0, s1, L, reg) in enumerate(wins):
+        sim = oracle.identity(oracle.pairwise_counts(bits, n, s0, s1), s1 - s0, 0)
+        pi, ps, _, G = oracle.pica2(sim[np.ix_(idx3, idx3)], 0.999, L, 5)
+        w1 = oracle.window_allpairs(bits, n, s0, s1, oracle.pack_mask(sel3), oracle.pack_mask(inA), oracle.pack_mask(inB), L)
+        D, _ = oracle.tajimas_d(3, float(w1["s_all"]), oracle.py_round(ps, 8))
+        t = ld[1 + k].split("\t")
+        assert t[:5] == [reg, str(L), "3", str(w1["s_all"]), f"{ps:.8f}"], (t, ps)
+        assert (t[5] == "NA" and D != D) or abs(float(t[5]) - D) <= 1e-9 * abs(D)
+    # --format all at the defaults: THRESHOLD / R_VALUE say 0.999 / 5 and the PICA_OUTPUT / PI columns are computed there;
+    # the h-fst table stays unrounded (run_h-fst.sh passes -r only when given); with --fst-round-digits it is h-fst.py -r
+    for fr in (None, 5, 3):
+        ra = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "impop_scan.py"), "--matrix", str(tmp_path / "m.npz"),
+                             "--bed", str(tmp_path / "w.bed"), "--format", "all", "-A", str(tmp_path / "A.txt"), "-B", str(tmp_path / "B.txt")]
+                            + ([] if fr is None else ["--fst-round-digits", str(fr)]), capture_output=True, text=True)
+        assert ra.returncode == 0, ra.stderr
+        la = ra.stdout.strip().split("\n")
+        for k, (s0, s1, L, reg) in enumerate(wins):
+            sim = oracle.identity(oracle.pairwise_counts(bits, n, s0, s1), s1 - s0, 0)
+            pi, ps, _, G = oracle.pica2(sim, 0.999, L, 5)
+            assert la[1 + k] == f"{reg}\t{L}\t0.999\t5\t{ps:.8f} (sequence length: {L})"
+            want, _ = oracle.hfst(sim, inA, inB, L, fr)
+            h = la[5 + k].split("\t")
+            for got, key in zip(h[2:], ("fst", "pi_a", "pi_b", "pi_xy", "dxy", "da")):
+                assert abs(float(got) - want[key]) <= 1.0000001e-8, (fr, key, got, want[key])
+            S = oracle.window_allpairs(bits, n, s0, s1, ones, oracle.pack_mask(inA), oracle.pack_mask(inB), L)["s_all"]
+            D, _ = oracle.tajimas_d(n, float(S), oracle.py_round(ps, 8))
+            t = la[9 + k].split("\t")
+            assert t[:5] == [reg, str(L), str(n), str(S), f"{ps:.8f}"]
+            assert (t[5] == "NA" and D != D) or abs(float(t[5]) - D) <= 1e-9 * abs(D)
+    # --format hfst -r N (run_h-fst.sh:76-78) on the all-pairs path
+    rh5 = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "impop_scan.py"), "--matrix", str(tmp_path / "m.npz"),
+                          "--bed", str(tmp_path / "w.bed"), "--format", "hfst", "-A", str(tmp_path / "A.txt"), "-B", str(tmp_path / "B.txt"),
+                          "-r", "3"], capture_output=True, text=True)
+    assert rh5.returncode == 0, rh5.stderr
+    for k, (s0, s1, L, reg) in enumerate(wins):
+        sim = oracle.identity(oracle.pairwise_counts(bits, n, s0, s1), s1 - s0, 0)
+        want, _ = oracle.hfst(sim, inA, inB, L, 3)
+        want0, _ = oracle.hfst(sim, inA, inB, L, None)
+        h = rh5.stdout.strip().split("\n")[1 + k].split("\t")
+        for got, key in zip(h[2:], ("fst", "pi_a", "pi_b", "pi_xy", "dxy", "da")):
+            assert abs(float(got) - want[key]) <= 1.0000001e-8, (key, got, want[key])
+        assert abs(want["pi_a"] - want0["pi_a"]) > 1e-7  # rounding to 3 digits really changes the table
+    bad_t = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "impop_scan.py"), "--matrix", str(tmp_path / "m.npz"),
+                            "--bed", str(tmp_path / "w.bed"), "--format", "hfst", "-A", str(tmp_path / "A.txt"), "-B", str(tmp_path / "B.txt"),
+                            "-t", "0.9"], capture_output=True, text=True)
+    assert bad_t.returncode == 2 and "only with --fst-method grouped" in bad_t.stderr
+    # the 3 x pi table with pica2's -t / -r (run_fst_impg.sh:73 passes them to all three runs)
+    r3t = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "impop_scan.py"), "--matrix", str(tmp_path / "m.npz"),
+                          "--bed", str(tmp_path / "w.bed"), "--format", "fst3pi", "-A", str(tmp_path / "A.txt"), "-B", str(tmp_path / "B.txt"),
+                          "-t", "0.995", "-r", "4"], capture_output=True, text=True)
+    assert r3t.returncode == 0, r3t.stderr
+    for k, (s0, s1, L, reg) in enumerate(wins):
+        sim = oracle.identity(oracle.pairwise_counts(bits, n, s0, s1), s1 - s0, 0)
+        t = r3t.stdout.strip().split("\n")[1 + k].split("\t")
+        assert t[:4] == [reg, str(L), "0.995", "4"]
+        for c, selx in ((4, inA), (5, inB), (6, inA | inB)):
+            ix = np.nonzero(selx)[0]
+            _, ps, _, _ = oracle.pica2(sim[np.ix_(ix, ix)], 0.995, L, 4)
+            assert abs(float(t[c]) - ps) <= 1.0000001e-8, (reg, c, t[c], ps)
     # thresholded pica2 goes through the all-pairs path
     r2 = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "impop_scan.py"), "--matrix", str(tmp_path / "m.npz"),
                          "--bed", str(tmp_path / "w.bed"), "--format", "pica2", "-t", "0.995", "-r", "4"], capture_output=True, text=True)
@@ -245,3 +313,47 @@ def test_batch_driver_node_level_matrix_with_weights(tmp_path):
     assert outs[("exp.npz", "pica2")] == outs[("node.npz", "pica2")]
     assert outs[("exp.npz", "hfst")] == outs[("node.npz", "hfst")]
     assert outs[("exp.npz", "hfst")].count("\n") == 4
+
+
+def test_batch_driver_rows_go_to_their_chromosome(tmp_path, oracle):
+    """run_pica2_impg.sh:139-151 builds REGION from each BED row's own chromosome: with one matrix per chromosome a
+    whole-genome BED works in one call, rows come back in BED order, and a row of a chromosome nobody holds is skipped
+    with a warning instead of being clamped onto another chromosome's matrix."""
+    from impop_amd import matrixio
+    rng = np.random.default_rng(77)
+    n = 16
+    mats = {}
+    for chrom, W, origin in (("chr3", 4000, 500), ("chr8", 2500, 0)):
+        m = (rng.random((n, W)) < 0.2).astype(np.uint8)
+        m[1] = m[0]
+        names = [f"S{i // 2:03d}#{i % 2 + 1}#{chrom}:{origin}-{origin + W}" for i in range(n)]
+        matrixio.save_matrix(str(tmp_path / f"{chrom}.npz"), matrixio.from_dense(m, names, origin=origin, contig=f"CHM13#0#{chrom}"))
+        mats[chrom] = (m, origin)
+    (tmp_path / "g.bed").write_text("chr8\t100\t900\nchr3\t1000\t2000\nchrX\t5\t50\nCHM13#0#chr8\t900\t2500\nchr3\t2000\t4500\n")
+    base = [sys.executable, os.path.join(ROOT, "scripts", "impop_scan.py"), "--bed", str(tmp_path / "g.bed"), "--format", "tajd"]
+    r = subprocess.run(base + ["--matrix", str(tmp_path / "chr3.npz"), str(tmp_path / "chr8.npz")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert "Skipping region CHM13#0#chrX:5-50: no matrix holds chromosome chrX" in r.stderr
+    lines = r.stdout.strip().split("\n")
+    want_rows = [("chr8", 100, 900), ("chr3", 1000, 2000), ("chr8", 900, 2500), ("chr3", 2000, 4500)]
+    assert len(lines) == 1 + len(want_rows)
+    ones = oracle.pack_mask(np.ones(n, np.uint8))
+    for line, (chrom, s, e) in zip(lines[1:], want_rows):
+        m, origin = mats[chrom]
+        bits = oracle.pack_hap_major(m)
+        s0, s1 = s - origin, e - origin
+        L = e - s
+        sim = oracle.identity(oracle.pairwise_counts(bits, n, s0, s1), s1 - s0, 0)
+        _, ps, _, _ = oracle.pica2(sim, 0.999, L, 5)
+        S = oracle.window_sitecount(bits, n, s0, s1, ones, ones, ones, L)["s_all"]
+        D, _ = oracle.tajimas_d(n, float(S), oracle.py_round(ps, 8))
+        t = line.split("\t")
+        assert t[:5] == [f"CHM13#0#{chrom}:{s}-{e}", str(L), str(n), str(S), f"{ps:.8f}"], (t, ps, S)
+        assert (t[5] == "NA" and D != D) or abs(float(t[5]) - D) <= 1e-9 * abs(D)
+    # one matrix only: the other chromosome's rows are skipped, not clamped
+    r1 = subprocess.run(base + ["--matrix", str(tmp_path / "chr8.npz")], capture_output=True, text=True)
+    assert r1.returncode == 0, r1.stderr
+    assert r1.stderr.count("no matrix holds chromosome chr3") == 2
+    assert r1.stdout.strip().split("\n")[1:] == [lines[1], lines[3]]
+    dup = subprocess.run(base + ["--matrix", str(tmp_path / "chr8.npz"), str(tmp_path / "chr8.npz")], capture_output=True, text=True)
+    assert dup.returncode == 2 and "two matrices for contig" in dup.stderr

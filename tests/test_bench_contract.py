@@ -27,7 +27,7 @@ def _last_json(text):
 
 def test_bench_single_gpu_line():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--n-windows", "96",
-                        "--no-cpu-baseline"], capture_output=True, text=True, cwd=ROOT)
+                        "--no-cpu-baseline", "--all-pairs-windows", "96"], capture_output=True, text=True, cwd=ROOT)
     assert r.returncode == 0, r.stderr
     d = _last_json(r.stdout)
     for k in REQUIRED:
@@ -41,6 +41,12 @@ def test_bench_single_gpu_line():
     for k in RANK_KEYS:  # the fields a bad N-GPU number is diagnosed from are present at N = 1 too
         assert k in d["ranks"], k
     assert len(d["ranks"]["kernel_ms_avg_per_rank"]) == 1
+    # the default command also measures the reference's DEFAULT chain (run_tajd.sh: pica2 -t 0.999 -r 5 -> %.8f -> tj_d) on
+    # the all-pairs path, parity-gated against the oracle inside bench.py, with its own roofline block
+    ap = d["secondary"]["all_pairs_mode"]
+    assert "error" not in ap, ap
+    assert ap["windows"] == 96 and ap["windows_per_s"] > 0 and ap["roofline"]["bound"] == "mfma" and ap["roofline"]["unit"] == "TFLOP/s"
+    assert abs(ap["roofline"]["frac"] - ap["roofline"]["achieved"] / ap["roofline"]["peak"]) < 1e-12
 
 
 def test_bench_one_rank_rccl_gather():
@@ -51,7 +57,7 @@ def test_bench_one_rank_rccl_gather():
     env = dict(os.environ, IMPOP_BENCH_FORCE_DIST="1")
     env.pop("MASTER_PORT", None)  # no launcher: bench.py must pick a free port itself, not a fixed one
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "6", "--warmup", "2", "--n-windows", "2000",
-                        "--no-cpu-baseline"], capture_output=True, text=True, cwd=ROOT, env=env, timeout=900)
+                        "--no-cpu-baseline", "--no-secondary"], capture_output=True, text=True, cwd=ROOT, env=env, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     d = _last_json(r.stdout)
     assert d["n_gpus"] == 1 and d["ranks"]["backend"] == "rccl" and d["ranks"]["gathered_records_checked"] is True

@@ -927,6 +927,49 @@ def test_pica2_nontransitive_tables_reproduce_reference_seed_order(ctx, oracle):
         ctx.pi_from_identity(np.eye(3), 0.5, None, None, seed_rank=np.array([0, 1, 1], np.uint32))
 
 
+def test_default_tajd_chain_all_pairs_path_vs_reference(ctx):
+    """The reference's DEFAULT Tajima chain — run_tajd.sh:9-10 (THRESHOLD=0.999, R_VALUE=5), :166 pica2.py -t T -l LENGTH -r R,
+    :174 first stdout token ("%.8f"), :180 tj_d.py -n SAMPLE_COUNT -p PI -S S_COUNT — on the all-pairs path, against values
+    captured from the real pica2.py + tj_d.py (tests/golden/bitmatrix.json: tajd_chain_default).  d_pi_mode 0 is that wiring:
+    pi_site through py_round(.., 8) into D, S over all rows of the window, n = members of the sample list."""
+    g = load_golden("bitmatrix.json")
+    seen = 0
+    for mrec in g["matrices"]:
+        n, W = mrec["n"], mrec["W"]
+        bm = ctx.upload(golden_bits(mrec), W)
+        inA = np.array(mrec["in_a"], np.uint8)
+        for kind in ("match", "dice"):
+            for label, mask in (("all", None), ("subset_a", inA)):
+                c = mrec["tajd_chain_default"][kind][label]
+                if c is None:
+                    continue
+                r = bm.pairwise_scan([(0, W, c["L"])], mask, None, None, kind=kind, threshold=0.999, round_digits=5)[0]
+                assert int(r["n_groups"]) == c["n_groups"] and int(r["s_all"]) == c["S"], (mrec["name"], kind, label)
+                assert rel_close(float(r["pi"]), fh(c["pi"]), REL, 1e-300) and rel_close(float(r["pi_site"]), fh(c["pi_site"]), REL, 1e-300)
+                assert f"{float(r['pi_site']):.8f}" == c["pi_text"]
+                want = fh(c["D"])
+                got = float(r["tajima_d"])
+                assert (got != got and want != want) or rel_close(got, want, REL), (mrec["name"], kind, label, got, want)
+                seen += 1
+        bm.free()
+    assert seen >= 18
+
+
+def test_default_tajd_chain_on_seeded_tables_per_hash_seed(ctx):
+    """... and on tables where the grouping depends on the reference's set order: pi from impop_pi_from_identity with the
+    captured order, its "%.8f" text into impop_tajimas_d, against the D the real chain printed under that hash seed."""
+    seen = 0
+    for t, run, sim, rank, _ in _seeded_cases():
+        for c in run["pica2"]:
+            pi, ps, _, G = ctx.pi_from_identity(sim, fh(c["threshold"]), c["round"], t["L"], seed_rank=rank)
+            assert f"{ps:.8f}" == c["pi_text"] and G == c["n_groups"]
+            got = float(ctx.tajimas_d(t["n"], float(c["S"]), float(f"{ps:.8f}"))[0])
+            want = fh(c["D"])
+            assert (got != got and want != want) or rel_close(got, want, REL), (t["name"], run["hashseed"], c, got)
+            seen += c["round"] == 5 and fh(c["threshold"]) == 0.999
+    assert seen >= 50
+
+
 def test_pica2_default_rule_is_a_reference_outcome_and_mirror_uses_set_order(ctx):
     """Without an order the engine seeds with the smallest remaining name: its pi must be one of the values the
     reference produced under the 40 captured hash seeds (chain5).  And the function-level mirror, handed a set,

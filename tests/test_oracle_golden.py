@@ -262,6 +262,56 @@ def test_pica2_default_seed_rule_is_a_value_the_reference_produces(oracle):
     assert any(rel_close(pi, w, TOL) for w in captured), (pi, captured)
 
 
+
+def default_chain(oracle_mod, sim, S, L, seed_rank=None):
+    """run_tajd.sh:166-180 on the oracle: pica2 -t 0.999 -l L -r 5 -> "%.8f" token -> tj_d -n n -S S"""
+    pi, ps, _, G = oracle_mod.pica2(sim, 0.999, L, 5, seed_rank=seed_rank)
+    text = f"{ps:.8f}"
+    return pi, ps, G, text, oracle_mod.tajimas_d(sim.shape[0], float(S), float(text))[0]
+
+
+def test_default_tajd_chain_goldens(oracle):
+    """The reference's DEFAULT Tajima chain (run_tajd.sh:9-10 THRESHOLD=0.999 R_VALUE=5; :166,174,180), captured from the
+    real pica2.py + tj_d.py: all haplotypes and a sample-list subset, both identity kinds."""
+    g = load_golden("bitmatrix.json")
+    seen = 0
+    for m in g["matrices"]:
+        n, W = m["n"], m["W"]
+        I = oracle.pairwise_counts(golden_bits(m), n, 0, W)
+        inA = np.array(m["in_a"], dtype=np.uint8)
+        for kind, kid in (("match", 0), ("dice", 1)):
+            sim = oracle.identity(I, W, kid)
+            for label, idx in (("all", np.arange(n)), ("subset_a", np.nonzero(inA)[0])):
+                c = m["tajd_chain_default"][kind][label]
+                if c is None:
+                    continue  # order dependent in the reference on this table
+                pi, ps, G, text, D = default_chain(oracle, sim[np.ix_(idx, idx)], c["S"], c["L"])
+                assert G == c["n_groups"] and text == c["pi_text"], (m["name"], kind, label, G, text, c)
+                assert rel_close(pi, fh(c["pi"]), TOL) and rel_close(ps, fh(c["pi_site"]), TOL)
+                want = fh(c["D"])
+                assert (D != D and want != want) or D == want, (m["name"], kind, label, D, want)  # same text in, same double out
+                assert oracle.py_round(ps, 8) == float(text)  # the device takes this route instead of printing
+                seen += 1
+    assert seen >= 18
+    tight = next(m for m in g["matrices"] if m["name"] == "n48_w12000_tight")
+    assert 1 < tight["tajd_chain_default"]["match"]["all"]["n_groups"] < tight["n"]
+
+
+def test_default_tajd_chain_on_seeded_tables(oracle):
+    """... and where the grouping depends on the set order: per captured PYTHONHASHSEED."""
+    seen = 0
+    for t, run, sim, rank, _ in seeded_cases():
+        for c in run["pica2"]:
+            pi, ps, _, G = oracle.pica2(sim, fh(c["threshold"]), t["L"], c["round"], seed_rank=rank)
+            text = f"{ps:.8f}"
+            assert text == c["pi_text"] and G == c["n_groups"]
+            D = oracle.tajimas_d(t["n"], float(c["S"]), float(text))[0]
+            want = fh(c["D"])
+            assert (D != D and want != want) or D == want
+            seen += c["round"] == 5 and fh(c["threshold"]) == 0.999
+    assert seen >= 50
+
+
 def test_hud_grouped_nontransitive_per_seed_order(oracle):
     n_checked = 0
     for t, run, sim, _, hud_rank in seeded_cases():

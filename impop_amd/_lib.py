@@ -22,7 +22,7 @@ class ImpopError(RuntimeError):
 
 
 ABI_VERSION = 2  # IMPOP_ABI_VERSION of include/impop_hip.h
-E_INVALID, E_NODEVICE, E_HIP, E_NOMEM, E_UNSUPPORTED = -1, -2, -3, -4, -5
+E_INVALID, E_NODEVICE, E_HIP, E_NOMEM, E_UNSUPPORTED, E_INTERNAL = -1, -2, -3, -4, -5, -6
 KEEP_SITE_BLOCKED, KEEP_HAP_MAJOR = 1, 2
 IDENTITY_MATCH, IDENTITY_DICE = 0, 1
 

@@ -124,6 +124,13 @@ IMPOP_API int impop_ctx_create(int device, void *stream, impop_ctx **out) {
         }
         ctx->own_stream = true;
     }
+    // the device error word exists from the start (kernels of several streams may point at it)
+    hipError_t ee = hipMalloc((void **)&ctx->d_err, sizeof(uint32_t));
+    if (ee == hipSuccess) ee = hipMemset(ctx->d_err, 0, sizeof(uint32_t));
+    if (ee != hipSuccess) {
+        impop_ctx_destroy(ctx);
+        return hip_fail(ee, "hipMalloc(device error word)", __FILE__, __LINE__);
+    }
     *out = ctx;
     return IMPOP_OK;
 }
@@ -134,6 +141,7 @@ IMPOP_API int impop_ctx_destroy(impop_ctx *ctx) {
     hipStreamSynchronize(ctx->stream);
     if (ctx->d_taj) hipFree(ctx->d_taj);
     if (ctx->d_queue) hipFree(ctx->d_queue);
+    if (ctx->d_err) hipFree(ctx->d_err);
     if (ctx->scratch) hipFree(ctx->scratch);
     for (void *a : ctx->d_aux)
         if (a) hipFree(a);
@@ -144,6 +152,23 @@ IMPOP_API int impop_ctx_destroy(impop_ctx *ctx) {
     delete ctx;
     return IMPOP_OK;
 }
+
+namespace impop {
+int ctx_err_fetch(impop_ctx *ctx) {
+    ctx->h_err = 0;
+    if (ctx->d_err) HIP_TRY(hipMemcpyAsync(&ctx->h_err, ctx->d_err, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    return IMPOP_OK;
+}
+int ctx_err_result(impop_ctx *ctx, const char *fn) {
+    if (!ctx->h_err) return IMPOP_OK;
+    const uint32_t w = ctx->h_err;
+    ctx->h_err = 0;
+    HIP_TRY(hipMemsetAsync(ctx->d_err, 0, sizeof(uint32_t), ctx->stream));
+    set_error("%s: internal device check failed (code 0x%x%s); the results of this call are invalid", fn, w,
+              (w & DEV_ERR_GROUPING) ? ": greedy grouping made no progress" : "");
+    return IMPOP_E_INTERNAL;
+}
+}  // namespace impop
 
 IMPOP_API int impop_ctx_synchronize(impop_ctx *ctx) {
     REQUIRE(ctx, "impop_ctx_synchronize: ctx is NULL");

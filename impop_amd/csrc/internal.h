@@ -88,6 +88,10 @@ struct impop_ctx {
     double *d_taj = nullptr;
     int64_t taj_n = -1;
     uint32_t *d_queue = nullptr;  // 8 task-queue heads of the persistent Gram kernel
+    // device error word (context.hip: ctx_err_word / ctx_err_fetch / ctx_err_result): kernels OR a bit in when an internal
+    // invariant fails (stats.hip: the grouping's progress bound), the call that launched them returns IMPOP_E_INTERNAL
+    uint32_t *d_err = nullptr;
+    uint32_t h_err = 0;
     // side stream + fork/join events (created on first use): independent latency-bound epilogue kernels of the
     // all-pairs path run next to each other instead of one after the other
     hipStream_t side = nullptr;
@@ -143,6 +147,9 @@ struct impop_matrix {
 
 namespace impop {
 int ctx_scratch(impop_ctx *ctx, size_t bytes, void **out);
+int ctx_err_fetch(impop_ctx *ctx);                 // enqueue its copy to the host (before the call's own stream sync)
+int ctx_err_result(impop_ctx *ctx, const char *fn);  // after that sync: IMPOP_OK, or IMPOP_E_INTERNAL (word cleared, message set)
+constexpr uint32_t DEV_ERR_GROUPING = 1u;            // greedy_groups_bits ran out of its progress bound
 int ctx_aux(impop_ctx *ctx, int slot, size_t bytes, void **out);
 // pairwise.hip: build (once) the bitmap of the sites that segregate among all haplotypes, m->d_segmap
 int ensure_segmap(impop_ctx *ctx, const impop_matrix *m);

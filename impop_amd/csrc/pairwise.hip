@@ -1297,7 +1297,11 @@ IMPOP_API int impop_pairwise_scan(impop_ctx *ctx, const impop_matrix *m, const i
                            want_s ? nP : 0u, params->d_pi_mode, want_s ? params->s_scope : 0, ctx->d_taj, d_o);
         PW_TRY(hipGetLastError());
         PW_TRY(hipMemcpyAsync(ov.data(), d_o, cnt * sizeof(impop_pairwise_stats), hipMemcpyDeviceToHost, ctx->stream));
+        rc = ctx_err_fetch(ctx);
+        if (rc) return fail(rc);
         PW_TRY(hipStreamSynchronize(ctx->stream));  // the staging vectors are reused by the next chunk
+        rc = ctx_err_result(ctx, "impop_pairwise_scan");  // a device-side consistency check tripped: no partial results
+        if (rc) return fail(rc);
         for (uint64_t k = 0; k < cnt; ++k) out_host[ord[base + k]] = ov[k];
         base += cnt;
     }

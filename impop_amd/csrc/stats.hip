@@ -99,6 +99,16 @@ __device__ inline uint64_t readlane_u64(uint64_t v, uint32_t l /*uniform*/) {
     const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), (int)l);
     return ((uint64_t)hi << 32) | lo;
 }
+// word w (< 128, PER LANE) of a 128-word set whose words l and l + 64 live in lane l's u0 / u1: a register exchange
+// (ds_bpermute_b32: lane i receives the source register of lane addr_i / 4).  Every lane of the wave must execute it.
+__device__ inline uint64_t lane_word(uint64_t u0, uint64_t u1, uint32_t w) {
+    const int a = (int)((w & 63) << 2);
+    const uint32_t lo0 = (uint32_t)__builtin_amdgcn_ds_bpermute(a, (int)(uint32_t)u0);
+    const uint32_t hi0 = (uint32_t)__builtin_amdgcn_ds_bpermute(a, (int)(uint32_t)(u0 >> 32));
+    const uint32_t lo1 = (uint32_t)__builtin_amdgcn_ds_bpermute(a, (int)(uint32_t)u1);
+    const uint32_t hi1 = (uint32_t)__builtin_amdgcn_ds_bpermute(a, (int)(uint32_t)(u1 >> 32));
+    return w < 64 ? (((uint64_t)hi0 << 32) | lo0) : (((uint64_t)hi1 << 32) | lo1);
+}
 
 struct JoinTest {  // "identity(seed, o) > threshold", as greedy_groups tests it
     bool by_cutoff;  // Gram + match: H <= H* (match_cutoff)
@@ -235,7 +245,6 @@ __device__ inline uint32_t greedy_groups_bits(const uint64_t *__restrict__ adj, 
     constexpr uint32_t ROWS_S = GG_ROWS;
     __shared__ uint32_t cand[64];
     __shared__ uint32_t sh_n, sh_G;
-    __shared__ uint64_t ufree[128];  // wave 0's free set, published for its own per-candidate look-ups
     if (m == 0) return 0;
     const uint32_t tid = threadIdx.x, lane = tid & 63;
     const uint32_t aw = bit_words(m), nh = aw / 4;
@@ -260,7 +269,10 @@ __device__ inline uint32_t greedy_groups_bits(const uint64_t *__restrict__ adj, 
     uint64_t u0 = initial(lane), u1 = initial(lane + 64);  // the free set (wave 0's copy is the one that counts)
     uint32_t G = 0, h_first = 0;
     __syncthreads();
-    // every block resolves at least one candidate: m blocks bound the loop whatever happens (a grid must drain)
+    // every block resolves at least one candidate: m blocks bound the loop whatever happens (a grid must drain).  Running
+    // out of the bound means an invariant of this function broke: the device error word makes the CALL fail
+    // (IMPOP_E_INTERNAL) instead of handing back partial groups.
+    bool done = false;
     for (uint32_t guard = 0; guard <= m; ++guard) {
         uint32_t mycand = 0;  // wave 0: lane b holds candidate b
         if (tid < 64) {  // the next up-to-B free positions, ascending: uniform work on words read across the lanes
@@ -293,7 +305,7 @@ __device__ inline uint32_t greedy_groups_bits(const uint64_t *__restrict__ adj, 
         }
         __syncthreads();
         const uint32_t n = __builtin_amdgcn_readfirstlane(sh_n);
-        if (n == 0) break;
+        if (n == 0) { done = true; break; }
         if (FROM_ADJ) {
             constexpr int RU = 8;  // candidate rows in flight per wave
             for (uint32_t b0 = tid >> 6; b0 < n; b0 += (ST / 64) * RU) {
@@ -347,20 +359,24 @@ __device__ inline uint32_t greedy_groups_bits(const uint64_t *__restrict__ adj, 
             // non-empty candidate is resolved the reference's way, the flags are taken again (the free set changed), and so
             // on.  With hundreds of groups per window most candidates are such singletons: one pass instead of a dependent
             // chain of LDS reads, lane reads and bit loops per candidate.
-            // `ufree` carries the free set from the lanes that hold it to the lanes that look candidates up: lanes of one
-            // wave talking through LDS, so volatile — to the compiler a lane's plain LDS traffic is private, and it forwarded
-            // a lane's own earlier store over what other lanes had written since (first version: groups counted twice).
-            volatile uint64_t *uf = ufree;
+            // The free set lives in the lanes (lane l: words l and l + 64) and the look-ups are lane-indexed reads of OTHER
+            // lanes' registers: ds_bpermute for the per-lane word of "is my candidate still free", v_readlane (uniform
+            // index) for the walk over the words of the set.  No memory in between — the first version passed the set
+            // through LDS, where the compiler may forward a lane's own earlier store over what other lanes wrote since
+            // (groups were counted twice; found by tools/soak_groups.py, pinned by test_grouping_soak_shape_regression).
             uint32_t pos = 0;
             while (pos < n) {
-                uf[lane] = u0; uf[lane + 64] = u1;
-                bool alive = false, nonempty = false;
                 const uint32_t c = mycand;
-                if (lane >= pos && lane < n) {
-                    alive = (uf[bit_word(c)] >> bit_lane(c)) & 1;
-                    if (alive)
-                        for (uint32_t w = 4 * (c >> 8); w < aw; ++w)
-                            if (rows[(uint64_t)lane * aw + w] & uf[w]) { nonempty = true; break; }
+                const bool mine = lane >= pos && lane < n;
+                // every lane of the wave executes the exchange (a bpermute reads the registers of active lanes only)
+                const uint64_t fw = lane_word(u0, u1, mine ? bit_word(c) : 0);
+                const bool alive = mine && ((fw >> bit_lane(c)) & 1);
+                bool nonempty = false;
+                const uint32_t w_first = 4 * (c >> 8);
+                for (uint32_t w = 0; w < aw; ++w) {  // uniform loop: word w of the free set is one scalar for the wave
+                    const uint64_t f = readlane_u64(w < 64 ? u0 : u1, w & 63);
+                    if (f == 0) continue;
+                    if (alive && w >= w_first && (rows[(uint64_t)lane * aw + w] & f)) nonempty = true;
                 }
                 const uint64_t bal_alive = __ballot(alive), bal_busy = __ballot(nonempty);
                 const uint32_t first = bal_busy ? (uint32_t)__ffsll((unsigned long long)bal_busy) - 1 : n;  // >= pos
@@ -402,6 +418,7 @@ __device__ inline uint32_t greedy_groups_bits(const uint64_t *__restrict__ adj, 
         __syncthreads();
         G = __builtin_amdgcn_readfirstlane(sh_G);
     }
+    if (!done && tid == 0 && S.err) atomicOr(S.err, DEV_ERR_GROUPING);
     return G;
 }
 
@@ -1150,7 +1167,9 @@ int launch_pica2(impop_ctx *ctx, const SimBatch &b, uint64_t n_problems, const u
     }
     if (lds > 48 * 1024)
         HIP_TRY(hipFuncSetAttribute((const void *)pica2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(pica2_kernel, dim3((uint32_t)n_problems), dim3(ST), lds, ctx->stream, b, d_idx, n_el, d_order,
+    SimBatch be = b;
+    be.err = ctx->d_err;  // the grouping's progress bound reports here (ctx_err_fetch / ctx_err_result in the caller)
+    hipLaunchKernelGGL(pica2_kernel, dim3((uint32_t)n_problems), dim3(ST), lds, ctx->stream, be, d_idx, n_el, d_order,
                        threshold, d_seq_len, d_out, d_group_of, split);
     HIP_TRY(hipGetLastError());
     if (chunks > 1) {
@@ -1207,7 +1226,9 @@ int launch_hud_grouped(impop_ctx *ctx, const SimBatch &b, uint64_t n_problems, c
     REQUIRE(lds <= lds_room, "grouped Fst: populations too large for the LDS-resident grouping");
     if (lds > 48 * 1024)
         HIP_TRY(hipFuncSetAttribute((const void *)hud_grouped_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(hud_grouped_kernel, dim3((uint32_t)n_problems), dim3(ST), lds, ctx->stream, b, d_ia, ma, d_ib, mb,
+    SimBatch be = b;
+    be.err = ctx->d_err;
+    hipLaunchKernelGGL(hud_grouped_kernel, dim3((uint32_t)n_problems), dim3(ST), lds, ctx->stream, be, d_ia, ma, d_ib, mb,
                        d_order_a, d_order_b, threshold, d_seq_len, d_out);
     HIP_TRY(hipGetLastError());
     return IMPOP_OK;
@@ -1308,7 +1329,11 @@ IMPOP_API int impop_pi_from_identity(impop_ctx *ctx, const double *ident, uint32
     std::vector<uint32_t> g(n ? n : 1);
     HIP_TRY(hipMemcpyAsync(&o, d_out, sizeof o, hipMemcpyDeviceToHost, ctx->stream));
     if (n) HIP_TRY(hipMemcpyAsync(g.data(), d_grp, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    rc = ctx_err_fetch(ctx);
+    if (rc) return rc;
     HIP_TRY(hipStreamSynchronize(ctx->stream));  // `order` (pageable) must outlive its copy
+    rc = ctx_err_result(ctx, "impop_pi_from_identity");
+    if (rc) return rc;
     if (pi) *pi = o.pi;
     if (pi_site) *pi_site = o.pi_site;
     if (n_groups) *n_groups = o.n_groups;
@@ -1545,7 +1570,11 @@ IMPOP_API int impop_fst_grouped_from_identity(impop_ctx *ctx, const double *iden
     if (rc) return rc;
     HfstOut o;
     HIP_TRY(hipMemcpyAsync(&o, d_out, sizeof o, hipMemcpyDeviceToHost, ctx->stream));
+    rc = ctx_err_fetch(ctx);
+    if (rc) return rc;
     HIP_TRY(hipStreamSynchronize(ctx->stream));  // ia / ib (pageable) must outlive the copies
+    rc = ctx_err_result(ctx, "impop_fst_grouped_from_identity");
+    if (rc) return rc;
     for (int k = 0; k < 6; ++k) out[k] = o.v[k];
     if (counts)
         for (int k = 0; k < 6; ++k) counts[k] = o.cnt[k];

@@ -25,6 +25,7 @@ struct SimBatch {
     // gram mode, optional: per-problem constant added to EVERY I_ij (diagonal included): the sites all haplotypes
     // carry, which a compacted matrix dropped (pairwise.hip)
     const uint32_t *add;
+    uint32_t *err;  // optional device error word (internal.h DEV_ERR_*): set by the launch_* functions
 };
 
 struct SimView {
@@ -43,6 +44,7 @@ struct SimView {
     uint32_t nseg;        // Gram matrices to add up (gram mode)
     uint64_t seg_stride;  // elements between them
     int64_t add;          // constant added to every Gram entry
+    uint32_t *err;        // device error word or nullptr
 };
 
 constexpr uint32_t SIM_TBL_N = 1024;  // 8 KB: LDS footprint decides the occupancy of the epilogue kernels
@@ -83,6 +85,7 @@ __device__ inline SimView sim_view(const SimBatch &b, uint64_t p) {
     v.tbl_n = 0;
     v.diag = nullptr;
     v.add = (b.gram && b.add) ? (int64_t)b.add[p] : 0;
+    v.err = b.err;
     return v;
 }
 

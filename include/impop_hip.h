@@ -42,7 +42,8 @@ typedef enum impop_status {
     IMPOP_E_NODEVICE = -2,  /* no HIP device / wrong architecture */
     IMPOP_E_HIP = -3,       /* a HIP runtime call failed */
     IMPOP_E_NOMEM = -4,
-    IMPOP_E_UNSUPPORTED = -5
+    IMPOP_E_UNSUPPORTED = -5,
+    IMPOP_E_INTERNAL = -6   /* a device-side consistency check tripped (results of the call are not to be used) */
 } impop_status;
 
 typedef struct impop_ctx impop_ctx;

@@ -1232,6 +1232,36 @@ def test_weighted_gram_equals_bp_expanded_matrix(ctx, oracle):
     big.free()
 
 
+def test_grouping_soak_shape_regression(ctx, oracle):
+    """Fixed-seed analogues of the shape tools/soak_groups.py failed on in round 2 (n = 1023, W = 1318, window 401-565,
+    dice, -t 0.99 -r 4: 1673 groups reported for 223 — more groups than elements; the free set of greedy_groups_bits went
+    between lanes through LDS and a lane's own store was forwarded over other lanes' writes) and its neighbours: mixed
+    blocks of singleton candidates and absorbing ones, partial last bit words, both identity kinds, a subset.  Group by
+    group against the oracle; since round 3 the exchange is a register exchange (ds_bpermute / v_readlane)."""
+    shapes = [(1023, 1318, 401, 565, "dice", 0.99, 4, 0.003), (1023, 1318, 401, 565, "match", 0.99, 4, 0.003),
+              (1024, 1318, 400, 566, "dice", 0.99, 4, 0.003), (1025, 1318, 401, 565, "dice", 0.99, None, 0.02),
+              (511, 900, 3, 420, "dice", 0.995, 4, 0.003), (1023, 1318, 401, 565, "dice", 0.9, 4, 0.02)]
+    for k, (n, W, a, b, kind, thr, rd, pflip) in enumerate(shapes):
+        for seed in (1, 2, 3):
+            rng = np.random.default_rng(1000 * k + seed)
+            nf = int(rng.integers(8, 40))
+            f = (rng.random((nf, W)) < 0.5).astype(np.uint8)
+            m = f[rng.integers(0, nf, size=n)] ^ (rng.random((n, W)) < pflip).astype(np.uint8)
+            bm = ctx.upload_dense(m, keep_hap_major=True)
+            sim = oracle.identity(oracle.pairwise_counts(oracle.pack_hap_major(m), n, a, b), b - a, 0 if kind == "match" else 1)
+            for inP in (None, (rng.random(n) < 0.9).astype(np.uint8)):
+                r = bm.pairwise_scan([(a, b, b - a)], inP, None, None, kind=kind, threshold=thr, round_digits=rd, s_scope=2)[0]
+                sel = np.arange(n) if inP is None else np.nonzero(inP)[0]
+                pi, ps, grp, G = oracle.pica2(sim[np.ix_(sel, sel)], thr, b - a, rd)
+                assert int(r["n_groups"]) == G, (n, W, a, b, kind, thr, rd, seed, int(r["n_groups"]), G)
+                assert G <= len(sel)
+                assert rel_close(float(r["pi"]), pi, REL, 1e-300), (n, kind, seed, float(r["pi"]), pi)
+            gpi, gps, ggrp, gG = ctx.pi_from_identity(sim, thr, rd, b - a)  # the dense-table entry: element by element
+            opi, ops, ogrp, oG = oracle.pica2(sim, thr, b - a, rd)
+            assert gG == oG and (ggrp == ogrp).all()
+            bm.free()
+
+
 def test_pica2_at_and_beyond_the_lds_limit(ctx, oracle):
     """The grouping state of a problem lives in LDS: 160 KB minus the kernel's static arrays (asked of the runtime).  A dense
     table just inside the limit runs (and agrees with the oracle); one beyond it is refused with an error, not launched."""

@@ -554,6 +554,64 @@ def main():
     pi1 = pica2.analyze_similarity_matrix({("x", "x"): 1.0}, {"x"}, 1, 1.0, 100, io.StringIO(), None)
     rag["degenerate"] = {"empty": [hx(v) for v in pi0], "single": [hx(v) for v in pi1]}
     json.dump({"meta": meta, **rag}, open(os.path.join(args.out, "ragged.json"), "w"), indent=1)
+    # ---------------------------------------------- Fst where Dxy - pi_xy cancels (tolerance policy)
+    # Every pair of haplotypes differs at exactly the same number of sites, so pi_A = pi_B = Dxy in exact arithmetic and
+    # Fst = Da = 0; h-fst.py sums (1 - sim) over Python sets (h-fst.py:141-171), so what it RETURNS is 0 or a value of the
+    # order of one rounding error of the sums (it moves with PYTHONHASHSEED).  Captured here under hash seed 0.
+    n, k_priv, k_shared = 30, 7, 100
+    W = k_shared + n * k_priv + 13
+    m = np.zeros((n, W), dtype=np.uint8)
+    m[:, :k_shared] = 1
+    for i in range(n):
+        m[i, k_shared + i * k_priv: k_shared + (i + 1) * k_priv] = 1
+    names = names_for(n, "chr4", 0, W)
+    inA = np.array([1 if i < 12 else 0 for i in range(n)], dtype=np.uint8)
+    inB = 1 - inA
+    I = np_counts(m)
+    canc = {"meta": meta, "n": n, "W": W, "names": names, "bits_u64_b64": b64(pack_rows(m)), "in_a": inA.tolist(), "in_b": inB.tolist(),
+            "kinds": {}}
+    for kind in ("match", "dice"):
+        sim = np_identity(I, W, kind)
+        d = sim_dict(sim, names)
+        A = {names[i] for i in range(n) if inA[i]}
+        B = {names[i] for i in range(n) if inB[i]}
+        runs = []
+        for Lx, rd in ((W, None), (W, 5), (None, None), (50000, 3)):
+            r = hfst.calculate_fst(d, set(A), set(B), Lx, rd)
+            runs.append({"L": Lx, "round": rd, "out": {k: hx(v) for k, v in r.items()}})
+        canc["kinds"][kind] = runs
+    json.dump(canc, open(os.path.join(args.out, "fst_cancel.json"), "w"), indent=1)
+
+    # ---------------------------------------------- allele counts per node column (scripts/wip/op-afs.py)
+    # The reference reads an `odgi paths -H` table (3 metadata columns, then one 0/1 column per node: op-afs.py:112) and, per
+    # column, returns the count and frequency of the value the FIRST data row holds (allele_freq returns inside the first
+    # iteration over its dict, op-afs.py:26-44); a monomorphic column makes main() fail (None is unpacked, :115), so the
+    # fixture has none.  Stored: the table text, what allele_freq returned per column, and main()'s counts_d / counts_f.
+    os.environ.setdefault("MPLBACKEND", "Agg")
+    afs_mod = load("ref_op_afs", os.path.join(sc, "wip", "op-afs.py"))
+    rng = np.random.default_rng(20251103)
+    n_path, n_node = 13, 57
+    tab = (rng.random((n_path, n_node)) < rng.random(n_node)[None, :] * 0.8 + 0.1).astype(np.int64)
+    for c in range(n_node):  # no monomorphic column
+        if tab[:, c].min() == tab[:, c].max():
+            tab[int(rng.integers(0, n_path)), c] ^= 1
+    pnames = [f"S{int(k) // 2:03d}#{int(k) % 2 + 1}#chr5:0-{n_node}" for k in rng.permutation(n_path)]  # file order != sorted order
+    header = ["path.name", "path.length", "node.count"] + [f"node.{c + 1}" for c in range(n_node)]
+    text = "\t".join(header) + "\n" + "".join(
+        "\t".join([pnames[r], str(100 + r), str(int(tab[r].sum()))] + [str(int(v)) for v in tab[r]]) + "\n" for r in range(n_path))
+    with tempfile.TemporaryDirectory() as td:
+        fp = os.path.join(td, "paths.tsv")
+        open(fp, "w").write(text)
+        df = afs_mod.read_file_to_matrix(fp)
+        cols, counts_d, counts_f = [], {}, {}
+        for column in df.columns[3:]:  # op-afs.py:112-118
+            label, value, count, freq = afs_mod.allele_freq(df[column].iloc[0:].tolist(), column)
+            cols.append({"label": str(label), "value": int(value), "count": int(count), "freq": hx(freq)})
+            counts_d.setdefault(int(value), []).append(int(count))
+            counts_f.setdefault(int(value), []).append(hx(freq))
+    json.dump({"meta": meta, "table_text": text, "n_path": n_path, "n_node": n_node, "columns": cols,
+               "counts_d": {str(k): v for k, v in sorted(counts_d.items())}, "counts_f": {str(k): v for k, v in sorted(counts_f.items())}},
+              open(os.path.join(args.out, "afs_table.json"), "w"), indent=1)
     seeded_fixture(sc, args.out, meta)
     print("wrote goldens to", os.path.abspath(args.out))
 

@@ -43,6 +43,15 @@ def rel_close(a, b, rel=1e-9, abs_=0.0):
     return abs(a - b) <= max(rel * max(abs(a), abs(b)), abs_)
 
 
+def stat_close(key, got, want, dxy, rel=1e-9):
+    """The tolerance policy of INTEGRATION.md §4: pi / pi_a / pi_b / pi_xy / Dxy / Tajima's D to 1e-9 relative.  Fst and Da are
+    DIFFERENCES (Da = Dxy - pi_xy, Fst = Da / Dxy): where Dxy and pi_xy cancel, what is left is the rounding error of the
+    sums, which in the reference itself moves with PYTHONHASHSEED (h-fst.py:141-171 sums over Python sets) — so they are
+    compared to 1e-9 relative OR an absolute floor of 1e-12 (Fst) / 1e-12 * Dxy (Da), whichever is larger."""
+    floor = 1e-12 if key == "fst" else 1e-12 * abs(dxy) if key == "da" else 0.0
+    return rel_close(got, want, rel, floor)
+
+
 @pytest.fixture(scope="session")
 def oracle():
     from oracle import oracle as o

@@ -169,3 +169,28 @@ def test_native_paths_table_parser_equals_python_reader(tmp_path):
     with pytest.raises(ValueError, match="expected >= 4"):
         extract.from_paths_table(str(few))
     assert extract._from_paths_table_native(str(tmp_path / "missing.tsv")) is None
+
+
+def test_paths_table_readers_vs_reference_op_afs(tmp_path):
+    """tests/golden/afs_table.json: an `odgi paths -H` table and what the REAL scripts/wip/op-afs.py (read_file_to_matrix +
+    allele_freq per node column, op-afs.py:112-118) returned for it — per column the count and frequency of the value the
+    file's first data row holds.  Both readers (native impop_paths_table_parse and the Python definition) must yield a
+    matrix whose column sums reproduce every captured count: count = c_s where the first row carries the node, n - c_s
+    where it does not."""
+    import json
+    import os
+    from conftest import ROOT
+    g = json.load(open(os.path.join(ROOT, "tests", "golden", "afs_table.json")))
+    p = tmp_path / "paths.tsv"
+    p.write_text(g["table_text"])
+    first_name = g["table_text"].split("\n")[1].split("\t")[0]
+    for native in (True, False):
+        mf = extract.from_paths_table(str(p), native=native)
+        assert mf.n_hap == g["n_path"] and mf.n_site == g["n_node"] and mf.names == sorted(mf.names)
+        m = impop_amd.unpack_hap_major(mf.bits, mf.n_site).astype(np.int64)
+        first = m[mf.names.index(first_name)]
+        c = m.sum(0)
+        for k, col in enumerate(g["columns"]):
+            assert int(first[k]) == col["value"], (native, col)
+            count = int(c[k]) if col["value"] == 1 else mf.n_hap - int(c[k])
+            assert count == col["count"] and count / mf.n_hap == float.fromhex(col["freq"]), (native, col, count)

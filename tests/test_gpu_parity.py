@@ -6,7 +6,7 @@ import random
 import numpy as np
 import pytest
 
-from conftest import fh, golden_bits, golden_counts, load_golden, rel_close
+from conftest import fh, golden_bits, golden_counts, load_golden, rel_close, stat_close
 from synth_ref import synth_matrix
 
 pytestmark = pytest.mark.gpu
@@ -447,6 +447,64 @@ def test_afs_matches_numpy(ctx):
         for (s0, s1), g in zip(wins[::37], got[::37]):
             assert (g == np.bincount(cs[s0:s1], minlength=nP + 1)).all(), (s0, s1, nP)
         assert (got.sum(axis=1) == np.array([b - a for a, b in wins])).all()
+    bm.free()
+
+
+def test_afs_and_site_counts_vs_reference_op_afs(ctx, tmp_path):
+    """(f)2 / (f)4 against the reference instead of numpy: the `odgi paths -H` table of tests/golden/afs_table.json through
+    impop_paths_table_parse -> upload -> impop_site_counts / impop_afs, against the per-column counts the real
+    scripts/wip/op-afs.py returned (count of the first row's value: c_s or n - c_s) and the vectors its main() histograms
+    (counts_d, op-afs.py:116)."""
+    import impop_amd
+    from impop_amd import extract
+    g = load_golden("afs_table.json")
+    p = tmp_path / "paths.tsv"
+    p.write_text(g["table_text"])
+    mf = extract.from_paths_table(str(p))
+    n, W = mf.n_hap, mf.n_site
+    bm = ctx.upload(mf.bits, W, keep_hap_major=False)
+    c = bm.site_counts(0, W)
+    for k, col in enumerate(g["columns"]):
+        assert (int(c[k]) if col["value"] == 1 else n - int(c[k])) == col["count"], col
+    # the spectrum: op-afs.py histograms counts_d[1] (carrier counts where row 0 carries the node) and counts_d[0]
+    # (non-carrier counts where it does not); as carrier counts both are one histogram over all node columns
+    want = np.zeros(n + 1, dtype=np.int64)
+    for v in g["counts_d"].get("1", []):
+        want[v] += 1
+    for v in g["counts_d"].get("0", []):
+        want[n - v] += 1
+    got = bm.afs([(0, W, W)])[0]
+    assert got.astype(np.int64).tolist() == want.tolist()
+    # a sub-window and a subset of paths against the same captured table
+    sub = np.zeros(n, np.uint8); sub[::2] = 1
+    m = impop_amd.unpack_hap_major(mf.bits, W)
+    assert bm.site_counts(5, 40, sub).tolist() == m[sub.astype(bool)][:, 5:40].sum(0).tolist()
+    bm.free()
+
+
+def test_fst_where_dxy_and_pi_xy_cancel_tolerance_policy(ctx):
+    """INTEGRATION.md §4 on the GPU paths: a matrix whose haplotype pairs are all equally distant (Fst = Da = 0 exactly; the
+    real h-fst.py returns -5e-16 ... -3e-15, tests/golden/fst_cancel.json).  pi / Dxy to 1e-9 relative; Fst and Da to 1e-9
+    relative or the absolute floors 1e-12 / 1e-12 * Dxy — through the streaming scan, the all-pairs path and the .sim entry."""
+    import base64
+    g = load_golden("fst_cancel.json")
+    n, W = g["n"], g["W"]
+    bits = np.frombuffer(base64.b64decode(g["bits_u64_b64"]), dtype=np.uint64).reshape(n, -1).copy()
+    inA, inB = np.array(g["in_a"], np.uint8), np.array(g["in_b"], np.uint8)
+    bm = ctx.upload(bits, W)
+    for kind in ("match", "dice"):
+        sim = bm.pairwise_identity(0, W, kind)
+        for c in g["kinds"][kind]:
+            want = {k: fh(v) for k, v in c["out"].items()}
+            got_pw = bm.pairwise_scan([(0, W, c["L"] or 0)], None, inA, inB, kind=kind, threshold=1.0, round_digits=c["round"], s_scope=2)[0]
+            got_sim, _ = ctx.fst_from_identity(sim, inA, inB, c["L"], c["round"])
+            routes = [("all-pairs", {k: float(got_pw[k]) for k in want}), (".sim", dict(zip(("fst", "pi_a", "pi_b", "pi_xy", "dxy", "da"), got_sim)))]
+            if kind == "match" and c["round"] is None:
+                rs = bm.scan([(0, W, c["L"] or 0)], None, inA, inB)[0]
+                routes.append(("streaming", {k: float(rs[k]) for k in want}))
+            for route, got in routes:
+                for k in want:
+                    assert stat_close(k, got[k], want[k], want["dxy"]), (route, kind, c["L"], c["round"], k, got[k], want[k])
     bm.free()
 
 

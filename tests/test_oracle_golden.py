@@ -7,7 +7,7 @@ import random
 import numpy as np
 import pytest
 
-from conftest import fh, golden_bits, golden_counts, load_golden, rel_close
+from conftest import stat_close, fh, golden_bits, golden_counts, load_golden, rel_close
 
 TOL = 1e-12  # oracle vs reference: same fp64 operations, only summation order may differ
 
@@ -321,3 +321,24 @@ def test_hud_grouped_nontransitive_per_seed_order(oracle):
                 assert rel_close(out[k], fh(w), 1e-11, 1e-18), (t["name"], run["hashseed"], c["threshold"], k, out[k], fh(w))
             n_checked += 1
     assert n_checked >= 50
+
+
+def test_fst_where_dxy_and_pi_xy_cancel(oracle):
+    """tests/golden/fst_cancel.json: every pair of haplotypes equally distant, so Fst = Da = 0 in exact arithmetic and the real
+    h-fst.py returns rounding noise (-5e-16 ... -3e-15 under PYTHONHASHSEED=0).  The tolerance policy (conftest.stat_close,
+    INTEGRATION.md §4) accepts the oracle's own noise; the non-cancelling fields agree to 1e-12."""
+    g = load_golden("fst_cancel.json")
+    n, W = g["n"], g["W"]
+    bits = np.frombuffer(__import__("base64").b64decode(g["bits_u64_b64"]), dtype=np.uint64).reshape(n, -1).copy()
+    I = oracle.pairwise_counts(bits, n, 0, W)
+    inA, inB = np.array(g["in_a"], np.uint8), np.array(g["in_b"], np.uint8)
+    for kind, kid in (("match", 0), ("dice", 1)):
+        sim = oracle.identity(I, W, kid)
+        for c in g["kinds"][kind]:
+            r, _ = oracle.hfst(sim, inA, inB, c["L"], c["round"])
+            want = {k: fh(v) for k, v in c["out"].items()}
+            assert abs(want["fst"]) < 1e-13 and abs(want["da"]) < 1e-13 * want["dxy"]  # the fixture really cancels
+            for k in ("pi_a", "pi_b", "pi_xy", "dxy"):
+                assert rel_close(r[k], want[k], TOL), (kind, c, k)
+            for k in ("fst", "da"):
+                assert stat_close(k, r[k], want[k], want["dxy"]), (kind, c, k, r[k], want[k])

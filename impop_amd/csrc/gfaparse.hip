@@ -157,10 +157,18 @@ IMPOP_API int impop_gfa_parse(const char *path, const char *ref_prefix, impop_gf
                 return done(IMPOP_E_INVALID);
             }
             int64_t L = seq == "*" ? 0 : (int64_t)seq.size();
+            if (L > 0xFFFFFFFFll) {
+                set_error("impop_gfa_parse: segment longer than 2^32 on line %llu", (unsigned long long)line_no);
+                return done(IMPOP_E_UNSUPPORTED);
+            }
             for (int k = 3;; ++k) {  // the last LN:i: tag wins
                 std::string_view tag;
                 if (!field(line, k, &tag)) break;
                 if (tag.size() >= 5 && tag.substr(0, 5) == "LN:i:") {
+                    if (tag.size() > 5 + 10) {  // more digits than a length below 2^32 has: the Python reader decides (no overflow here)
+                        set_error("impop_gfa_parse: unusual LN tag on line %llu", (unsigned long long)line_no);
+                        return done(IMPOP_E_UNSUPPORTED);
+                    }
                     int64_t v = 0;
                     bool neg = false, okv = true;
                     size_t i = 5;
@@ -170,7 +178,7 @@ IMPOP_API int impop_gfa_parse(const char *path, const char *ref_prefix, impop_gf
                         if (tag[i] < '0' || tag[i] > '9') okv = false;
                         else v = v * 10 + (tag[i] - '0');
                     }
-                    if (!okv || tag.size() > 5 + 18) {  // anything int() might read differently: the Python reader decides
+                    if (!okv || v > 0xFFFFFFFFll) {  // anything int() might read differently, or a length the 32-bit weights cannot hold
                         set_error("impop_gfa_parse: unusual LN tag on line %llu", (unsigned long long)line_no);
                         return done(IMPOP_E_UNSUPPORTED);
                     }
@@ -283,6 +291,11 @@ IMPOP_API int impop_gfa_parse(const char *path, const char *ref_prefix, impop_gf
             if (dash != std::string::npos && colon != std::string::npos && colon + 1 < dash && dash + 1 < rn.size() &&
                 all_digits(std::string_view(rn).substr(colon + 1, dash - colon - 1)) && all_digits(std::string_view(rn).substr(dash + 1)))
                 ref_start = strtoll(rn.c_str() + colon + 1, nullptr, 10);
+        }
+        if (ref_start > (int64_t)1 << 60) {  // coordinates are summed below: keep them far from the end of int64
+            set_error("impop_gfa_parse: reference start beyond 2^60");
+            delete G;
+            return done(IMPOP_E_UNSUPPORTED);
         }
         G->pos.assign(n_seg, -1);
         int64_t off = ref_start;

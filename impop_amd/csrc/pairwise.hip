@@ -382,7 +382,8 @@ __device__ __forceinline__ void gram_task_fp4(const uint32_t *__restrict__ rb, u
             const int b = DIAG ? (i < 3 ? i : i < 5 ? i - 2 : 2) : i % 3;                                 \
             if (DIAG) mfma_asm(acc[a][b], CURF.a[a], CURF.a[b]);                                          \
             else mfma_asm(acc[a][b], CURF.a[a], CURF.b[b]);                                               \
-            if (DO_LOAD && i < (DIAG ? 3 : 6)) load_one(LOADC, i, SOFF);                                  \
+            if (DO_LOAD && !(IMPOP_GRAM_ABLATE & 2) && i < (DIAG ? 3 : 6)) load_one(LOADC, i, SOFF);      \
+            if (IMPOP_GRAM_ABLATE & 1) continue; /* timing-only build: no expansion VALU */               \
             if (DIAG) {                                                                                   \
                 if (i == 0) lo_masked(NXTF.a[0], xa0, D ? SRC.a[0].y : SRC.a[0].x, M);                    \
                 if (i == 1) hi_planes(NXTF.a[0], xa0);                                                    \
@@ -446,6 +447,18 @@ __device__ __forceinline__ void gram_task_fp4(const uint32_t *__restrict__ rb, u
                     lo_plain(F.b[g], C0.b[g].x);
                     hi_planes(F.b[g], C0.b[g].x);
                 }
+#if IMPOP_GRAM_ABLATE & 1  // timing-only build without the in-loop expansion: G needs realistic contents too
+#pragma unroll
+                for (int g = 0; g < 3; ++g) {
+                    lo_masked(G.a[g], xm, C1.a[g].y, m0);
+                    hi_planes(G.a[g], xm);
+                }
+#pragma unroll
+                for (int g = 0; g < NB; ++g) {
+                    lo_plain(G.b[g], C1.b[g].y);
+                    hi_planes(G.b[g], C1.b[g].y);
+                }
+#endif
                 asm volatile("s_nop 7");  // VALU-written operands -> first MFMA (the compiler cannot see into the asm)
             }
             // no early exit (extra loop exits make the compiler merge 144 accumulators and spill): a slice

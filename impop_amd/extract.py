@@ -16,6 +16,14 @@ import numpy as np
 from .matrixio import MatrixFile, from_dense
 
 
+def _contig_of(ref_path_name: str) -> str:
+    """The contig a matrix's coordinates refer to: the reference path's name without its ":start-end" range
+    (`CHM13#0#chr7:1000-51000` -> `CHM13#0#chr7`) — what the batch driver matches a BED row's chromosome with
+    (REGION = prefix + chr, run_pica2_impg.sh:139-151)."""
+    import re
+    return re.sub(r":\d+-\d+$", "", ref_path_name)
+
+
 def _handle_to_matrix(lib, h, with_lengths: bool, ref_prefix: Optional[str]) -> MatrixFile:
     """names / bits / (lengths, positions) out of a native parser handle (impop_gfa_*)."""
     import ctypes as C
@@ -38,7 +46,7 @@ def _handle_to_matrix(lib, h, with_lengths: bool, ref_prefix: Optional[str]) -> 
         pos = np.zeros(n_seg.value, dtype=np.int64)
         _lib.check(lib.impop_gfa_positions(h, pos.ctypes.data_as(C.POINTER(C.c_int64))))
         mf.site_pos = pos
-        mf.contig = ref_prefix or ""
+        mf.contig = _contig_of(names[ref_row.value]) if 0 <= ref_row.value < len(names) else (ref_prefix or "")
     return mf
 
 
@@ -195,5 +203,5 @@ def from_gfa(path: str, ref_prefix: Optional[str] = None, expand_bp: bool = True
         mf.site_weight = np.maximum(lens, 0).astype(np.uint32)
     if node_pos is not None:
         mf.site_pos = node_pos
-        mf.contig = ref_prefix or ""
+        mf.contig = _contig_of([t for t in paths if t[0].startswith(ref_prefix)][0][0])
     return mf

@@ -151,6 +151,7 @@ def test_batch_driver_tables(tmp_path, oracle):
                           "--bed", str(tmp_path / "w.bed"), "--format", "hfst", "-A", str(tmp_path / "A.txt"), "-B", str(tmp_path / "B.txt"),
                           "-r", "3"], capture_output=True, text=True)
     assert rh5.returncode == 0, rh5.stderr
+    changed = False
     for k, (s0, s1, L, reg) in enumerate(wins):
         sim = oracle.identity(oracle.pairwise_counts(bits, n, s0, s1), s1 - s0, 0)
         want, _ = oracle.hfst(sim, inA, inB, L, 3)
@@ -158,7 +159,8 @@ def test_batch_driver_tables(tmp_path, oracle):
         h = rh5.stdout.strip().split("\n")[1 + k].split("\t")
         for got, key in zip(h[2:], ("fst", "pi_a", "pi_b", "pi_xy", "dxy", "da")):
             assert abs(float(got) - want[key]) <= 1.0000001e-8, (key, got, want[key])
-        assert abs(want["pi_a"] - want0["pi_a"]) > 1.5e-8  # rounding to 3 digits really changes the printed table
+        changed = changed or abs(want["pi_a"] - want0["pi_a"]) > 1.5e-8
+    assert changed  # rounding to 3 digits really changes the printed table somewhere
     bad_t = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "impop_scan.py"), "--matrix", str(tmp_path / "m.npz"),
                             "--bed", str(tmp_path / "w.bed"), "--format", "hfst", "-A", str(tmp_path / "A.txt"), "-B", str(tmp_path / "B.txt"),
                             "-t", "0.9"], capture_output=True, text=True)

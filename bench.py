@@ -280,6 +280,157 @@ def cpu_baseline(bm, windows, in_a, in_b, budget_s=12.0):
     }, first
 
 
+def run_config4(args, ctx, stream, dev, rank, world, backend, use_dist):
+    """BASELINE configs[3]: whole-genome pi + Fst + D scan in 10 kb windows at a 5 kb step, sharded over the GPUs of a node with
+    ONE gather of records (the shape of doc/how_pi.md:40-42; the loops of run_tajd.sh:103 / run_h-fst.sh:155 over a genome BED).
+
+    One global window list.  impop_shard_windows gives rank r a contiguous window range and the site slab it touches — its share of
+    the genome plus a (window - step) halo towards the next rank — and the rank generates ONLY that slab (the synthetic generator is
+    counter-based on the global site index, impop_matrix_synthetic_slab).  A step = every rank scans its windows (each site is read
+    once: overlapping windows share elementary segments) and the 128-byte records are all-gathered (uneven shards padded).  Strong
+    scaling: the total work is fixed, `value` = windows of the whole list / time of a step.  Checked inside the run: the records
+    gathered by the first and by the timed steps are this rank's own; on rank 0, windows on both sides of every shard boundary
+    (the ones that need the halo), the first and the last are re-scanned from a small slab generated on its own and must come
+    back byte-identical from whichever rank computed them."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    import impop_amd
+    from impop_amd import engine
+
+    n, G, Wn, step = args.n_hap, args.genome_sites, args.c4_window, args.c4_step
+    seed = 20251031
+    all_wins = impop_amd.fixed_windows(G, Wn, step)
+    NWt = len(all_wins)
+    first, cnt, s0, s1 = engine.shard_windows_c(all_wins, world, rank)
+    a0 = s0 // 64 * 64                      # slabs start on a 64-site block
+    t0 = time.perf_counter()
+    bm = ctx.synthetic(n, max(s1 - a0, 64), seed=seed, site_begin=a0)
+    ctx.synchronize()
+    t_gen = time.perf_counter() - t0
+    loc = all_wins[first:first + cnt].copy()
+    loc["site_begin"] -= np.uint64(a0)
+    loc["site_end"] -= np.uint64(a0)
+    in_a = np.zeros(n, np.uint8); in_a[: min(140, n)] = 1
+    in_b = np.zeros(n, np.uint8); in_b[min(140, n): min(240, n)] = 1
+    plan = bm.plan(loc, None, in_a, in_b, tile_blocks=args.tile_blocks)
+    counts = [engine.shard_windows_c(all_wins, world, r)[1] for r in range(world)]
+    firsts = [engine.shard_windows_c(all_wins, world, r)[0] for r in range(world)]
+    cap = max(max(counts), 1)
+    if rank == 0:
+        log(f"[bench config4] {NWt} windows of {Wn} sites at step {step} over {G} sites; rank 0 holds sites [{a0}, {s1}) = "
+            f"{bm.device_bytes / 1e9:.2f} GB, generated in {t_gen:.2f} s; shards {counts}")
+    with torch.cuda.stream(stream):
+        bufs = [torch.zeros(cap * 128, dtype=torch.uint8, device=dev) for _ in range(2)]
+        gdev = dev if backend == "nccl" else torch.device("cpu")
+        gathered = [torch.empty(world * cap * 128, dtype=torch.uint8, device=gdev) for _ in range(2)] if use_dist else None
+    works = [None, None]
+    counter = [0]
+
+    def step_once():
+        b = counter[0] & 1
+        counter[0] += 1
+        with torch.cuda.stream(stream):
+            if works[b] is not None:
+                works[b].wait(); works[b] = None
+            plan.launch(bufs[b].data_ptr())
+            if use_dist:
+                src = bufs[b] if backend == "nccl" else bufs[b].cpu()
+                works[b] = dist.all_gather_into_tensor(gathered[b], src, async_op=True)
+
+    def drain():
+        with torch.cuda.stream(stream):
+            for b in (0, 1):
+                if works[b] is not None:
+                    works[b].wait(); works[b] = None
+        torch.cuda.synchronize(dev)
+
+    def all_records(b):
+        """the gathered buffer -> records of the whole list in global window order (padding dropped)"""
+        if not use_dist:
+            return np.frombuffer(bufs[b].cpu().numpy().tobytes(), dtype=impop_amd.STATS_DTYPE)[:cnt].copy()
+        raw = gathered[b].cpu().numpy().tobytes()
+        parts = [np.frombuffer(raw[r * cap * 128: r * cap * 128 + counts[r] * 128], dtype=impop_amd.STATS_DTYPE) for r in range(world)]
+        return np.concatenate(parts)
+
+    step_once(); drain()
+    mine = np.frombuffer(bufs[0].cpu().numpy().tobytes(), dtype=impop_amd.STATS_DTYPE)[:cnt].copy()
+    ref_all = all_records(0)
+    assert ref_all[first:first + cnt].tobytes() == mine.tobytes(), f"rank {rank}: gathered records differ from local (first step)"
+    assert len(ref_all) == NWt
+    if rank == 0:  # windows that straddle shard boundaries (they need the halo), the first and the last: from slabs of their own
+        sample = {0, NWt - 1}
+        for r in range(1, world):
+            if counts[r]:
+                sample |= {max(firsts[r] - 1, 0), firsts[r], min(firsts[r] + 1, NWt - 1)}
+        for wi in sorted(sample):
+            wb, we = int(all_wins[wi]["site_begin"]), int(all_wins[wi]["site_end"])
+            b0 = wb // 64 * 64
+            sm = ctx.synthetic(n, we - b0, seed=seed, site_begin=b0)
+            one = sm.scan([(wb - b0, we - b0, int(all_wins[wi]["seq_len"]))], None, in_a, in_b)
+            sm.free()
+            assert one[0].tobytes() == ref_all[wi].tobytes(), f"config4: window {wi} differs from its stand-alone scan"
+        log(f"[bench config4] {len(sample)} windows (shard boundaries, first, last) byte-identical to stand-alone scans")
+    for _ in range(args.warmup):
+        step_once()
+    drain()
+    plan.timing(True)
+    if use_dist:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step_once()
+    drain()
+    if use_dist:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    elapsed = time.perf_counter() - t0
+    kern_ms, launches = plan.elapsed()
+    plan.timing(False)
+    for b in (0, 1):
+        if args.steps > b:
+            assert all_records(b).tobytes() == ref_all.tobytes(), f"rank {rank}: records of a timed step differ from the checked first step"
+    per = [elapsed, kern_ms / max(launches, 1), float(bm.device_bytes), float(cnt)]
+    if use_dist:
+        t = torch.tensor(per, dtype=torch.float64, device=gdev)
+        allr = torch.empty(world * 4, dtype=torch.float64, device=gdev)
+        dist.all_gather_into_tensor(allr, t)
+        allr = allr.cpu().numpy().reshape(world, 4)
+    else:
+        allr = np.array([per])
+    elapsed = float(allr[:, 0].max())
+    if rank == 0:
+        sites_read = float(allr[:, 2].sum()) / bm.bytes_per_site  # every rank reads its slab once per step
+        slow = int(allr[:, 1].argmax())
+        algo_bytes_slow = n * (allr[slow, 2] / bm.bytes_per_site) / 8.0
+        achieved = algo_bytes_slow / (allr[slow, 1] / 1e3) / 1e9
+        out = {
+            "metric": "windows/sec (pi+Fst+D) for 465-hap HPRC, whole-genome 10 kb sliding windows", "value": NWt * args.steps / elapsed,
+            "unit": "windows/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+            "config": {"workload": f"BASELINE configs[3]: whole-genome scan, {NWt} windows of {Wn} sites at step {step} over {G} sites, {n} "
+                                   f"haplotypes, pi + Hudson Fst (A=140 vs B=100) + Tajima's D + S per window; windows sharded over {world} "
+                                   f"GPU(s) (contiguous ranges + {Wn - step}-site halo), one all_gather of records per step",
+                       "n_hap": n, "window_sites": Wn, "step_sites": step, "genome_sites": G, "windows_total": NWt,
+                       "windows_per_rank": [int(c) for c in allr[:, 3]], "slab_GB_per_rank": [float(x) / 1e9 for x in allr[:, 2]],
+                       "sites_read_per_step": sites_read, "parallelism": f"windows sharded over {world} GPU(s), one all_gather of records per step"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": None, "kernel": "scan_tiles_kernel (slowest rank)", "kernel_ms_avg": float(allr[slow, 1]),
+                         "algorithmic_bytes_per_launch": algo_bytes_slow},
+            "cpu_baseline": None,
+            "ranks": {"backend": ("rccl" if backend == "nccl" else "gloo-rehearsal") if use_dist else None,
+                      "elapsed_s_min": float(allr[:, 0].min()), "elapsed_s_max": float(allr[:, 0].max()),
+                      "kernel_ms_avg_per_rank": [float(x) for x in allr[:, 1]], "gathered_records_checked": bool(use_dist),
+                      "boundary_windows_checked_against_standalone_scans": True},
+            "secondary": None,
+        }
+        print(json.dumps(out), flush=True)
+    plan.destroy()
+    bm.free()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -289,6 +440,13 @@ def main():
     ap.add_argument("--window", type=int, default=50000)
     ap.add_argument("--n-windows", type=int, default=4854, help="per GPU; 4854 = chr2 (242.7 Mb) in 50 kb windows")
     ap.add_argument("--tile-blocks", type=int, default=0)
+    ap.add_argument("--config4", action="store_true",
+                    help="BASELINE configs[3] instead of the headline: ONE whole-genome list of sliding windows (--c4-window / "
+                         "--c4-step over --genome-sites), cut into contiguous ranges over the ranks (impop_shard_windows), every rank "
+                         "holding only its slab + halo, one all-gather of the records per step; strong scaling")
+    ap.add_argument("--genome-sites", type=int, default=3_100_000_000, help="--config4: sites of the whole genome (3.1 Gb = 186 GB at 465 haplotypes)")
+    ap.add_argument("--c4-window", type=int, default=10000)
+    ap.add_argument("--c4-step", type=int, default=5000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--secondary", action="store_true",
                     help="also measure the variable-sites-only scan and the all-pairs mode on the compacted matrix (under "
@@ -352,6 +510,12 @@ def main():
     stream = torch.cuda.Stream(dev)
     assert stream.cuda_stream != 0
     ctx = impop_amd.Context(local_rank, stream=stream.cuda_stream)
+    if args.config4:
+        run_config4(args, ctx, stream, dev, rank, world, backend, use_dist)
+        ctx.close()
+        if use_dist:
+            dist.destroy_process_group()
+        return
     n, W, NW = args.n_hap, args.window, args.n_windows
     n_site = W * NW
     t0 = time.perf_counter()

@@ -143,12 +143,12 @@ struct SynthDev {
 // tables: fmask[f*wps + k] (haplotypes of founder f in dword k), then valid[k]
 __global__ __launch_bounds__(256) void synth_sb_kernel(SynthDev p, const uint32_t *__restrict__ tables, uint32_t wps,
                                                        uint32_t G, uint32_t r, uint64_t n_block, uint64_t n_site,
-                                                       uint32_t *__restrict__ sb) {
+                                                       uint64_t site0, uint32_t *__restrict__ sb) {
     const uint32_t lane = threadIdx.x & 63;
     const uint64_t b = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (b >= n_block) return;
-    const uint64_t s = b * 64 + lane;
-    const bool live = s < n_site;
+    const bool live = b * 64 + lane < n_site;
+    const uint64_t s = site0 + b * 64 + lane;  // the generator is counter-based on the GLOBAL site index: a slab is a cut of the whole
     const uint32_t anc = (synth_hash(p.seed, 1, s) & 1ull) ? 0xFFFFFFFFu : 0u;
     uint32_t fl = 0;
     for (uint32_t f = 0; f < p.n_founder; ++f)
@@ -265,8 +265,14 @@ IMPOP_API int impop_matrix_upload(impop_ctx *ctx, const uint64_t *bits, uint32_t
 
 IMPOP_API int impop_matrix_synthetic(impop_ctx *ctx, uint32_t n_hap, uint64_t n_site, const impop_synth_params *p,
                                      uint32_t keep_flags, impop_matrix **out) {
+    return impop_matrix_synthetic_slab(ctx, n_hap, 0, n_site, p, keep_flags, out);
+}
+
+IMPOP_API int impop_matrix_synthetic_slab(impop_ctx *ctx, uint32_t n_hap, uint64_t site_begin, uint64_t n_site,
+                                          const impop_synth_params *p, uint32_t keep_flags, impop_matrix **out) {
     REQUIRE(ctx && out && p, "impop_matrix_synthetic: NULL argument");
     *out = nullptr;
+    REQUIRE(site_begin + n_site >= site_begin, "impop_matrix_synthetic_slab: site range wraps");
     REQUIRE(n_hap >= 1 && n_hap <= (1u << 20), "impop_matrix_synthetic: bad n_hap %u", n_hap);
     REQUIRE(p->n_founder >= 1 && p->n_founder <= 32, "impop_matrix_synthetic: n_founder must be 1..32");
     REQUIRE(p->p_founder >= 0 && p->p_founder < 1 && p->p_private_word >= 0 && p->p_private_word < 1,
@@ -304,7 +310,7 @@ IMPOP_API int impop_matrix_synthetic(impop_ctx *ctx, uint32_t n_hap, uint64_t n_
             return fail(IMPOP_E_INVALID);
         }
         hipLaunchKernelGGL(synth_sb_kernel, dim3((uint32_t)grid), dim3(256), 0, ctx->stream, sp, (const uint32_t *)d_tab,
-                           wps, m->g.G, m->g.r, m->g.n_block, n_site, m->d_sb);
+                           wps, m->g.G, m->g.r, m->g.n_block, n_site, site_begin, m->d_sb);
         if ((e = hipGetLastError()) != hipSuccess) return fail(hip_fail(e, "synth_sb_kernel", __FILE__, __LINE__));
         if (want_hm) {
             rc = launch_sb_to_hm(ctx, m->d_sb, m->g, 0, m->g.n_block, m->d_rb, 0, m->n_hap_pad, m->rb_nb);

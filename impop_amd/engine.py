@@ -175,11 +175,13 @@ class Context:
         return self.upload(pack_hap_major(m), m.shape[1], keep_hap_major)
 
     def synthetic(self, n_hap: int, n_site: int, seed: int = 20251031, n_founder: int = 8, p_founder: float = 1e-3,
-                  p_private_word: float = 3.2e-3, keep_hap_major: bool = False) -> "BitMatrix":
+                  p_private_word: float = 3.2e-3, keep_hap_major: bool = False, site_begin: int = 0) -> "BitMatrix":
+        """Sites [site_begin, site_begin + n_site) of the synthetic chromosome of `seed` (counter-based generator: a slab is
+        a cut of the whole, impop_matrix_synthetic_slab); site 0 of the result is global site `site_begin`."""
         p = SynthParams(int(seed), int(n_founder), float(p_founder), float(p_private_word))
         h = C.c_void_p()
         keep = KEEP_SITE_BLOCKED | (KEEP_HAP_MAJOR if keep_hap_major else 0)
-        check(self._lib.impop_matrix_synthetic(self.handle, int(n_hap), int(n_site), C.byref(p), keep, C.byref(h)))
+        check(self._lib.impop_matrix_synthetic_slab(self.handle, int(n_hap), int(site_begin), int(n_site), C.byref(p), keep, C.byref(h)))
         return BitMatrix(self, h)
 
     # ---- statistics on a given identity matrix (the .sim drop-in path) -----------------

@@ -91,6 +91,11 @@ typedef struct impop_synth_params {
 } impop_synth_params;
 int impop_matrix_synthetic(impop_ctx *ctx, uint32_t n_hap, uint64_t n_site, const impop_synth_params *p,
                            uint32_t keep_flags, impop_matrix **out);
+/* Sites [site_begin, site_begin + n_site) of the same synthetic chromosome (the generator is counter-based on the global
+ * site index): what a rank of a sharded scan holds — its window range's slab plus halo — without anybody
+ * ever materialising the whole matrix.  Site 0 of the returned matrix is global site `site_begin`. */
+int impop_matrix_synthetic_slab(impop_ctx *ctx, uint32_t n_hap, uint64_t site_begin, uint64_t n_site,
+                                const impop_synth_params *p, uint32_t keep_flags, impop_matrix **out);
 
 /* Copy sites [site_begin, site_end) back to the host in hap-major layout
  * (bit 0 of word 0 of each row = site_begin). */

@@ -79,3 +79,38 @@ def test_bench_two_ranks_gloo_rehearsal():
     assert d["config"]["windows_per_gpu"] == 1500  # a scan of ~0.7 ms per rank: ordering bugs would show
     assert d["ranks"]["backend"] == "gloo-rehearsal" and d["ranks"]["gathered_records_checked"] is True
     assert len(d["ranks"]["kernel_ms_avg_per_rank"]) == 2
+
+
+def test_bench_config4_sharded_sliding_windows():
+    """BASELINE configs[3] through the rank-aware path: ONE global list of 10 kb windows at a 5 kb step over a (here: small) genome,
+    impop_shard_windows ranges + halo, every rank generating only its slab, one gather per step.  bench.py asserts inside that the
+    records gathered by the first and the timed steps are the ranks' own and that the windows around every shard boundary equal
+    stand-alone scans byte for byte.  Here: two ranks over gloo sharing the box's one GPU, then the RCCL path with the one rank a
+    one-GPU box allows; both must report the same windows as a plain one-rank run."""
+    base = [os.path.join(ROOT, "bench.py"), "--config4", "--genome-sites", "20000123", "--steps", "3", "--warmup", "1"]
+    one = subprocess.run([sys.executable] + base, capture_output=True, text=True, cwd=ROOT, timeout=900)
+    assert one.returncode == 0, one.stderr[-3000:]
+    d1 = _last_json(one.stdout)
+    assert d1["scaling"] == "strong" and d1["n_gpus"] == 1 and "configs[3]" in d1["config"]["workload"]
+    assert d1["config"]["windows_total"] == 4000 and d1["config"]["window_sites"] == 10000 and d1["config"]["step_sites"] == 5000
+    # every site is read once although every site lies in two windows
+    assert abs(d1["config"]["sites_read_per_step"] - 20000123) < 64 * 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, IMPOP_BENCH_BACKEND="gloo")
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", str(port)] + base + ["--gpus", "2"], capture_output=True, text=True, cwd=ROOT, env=env, timeout=900)
+    assert two.returncode == 0, two.stderr[-3000:]
+    d2 = _last_json(two.stdout)
+    assert d2["n_gpus"] == 2 and d2["config"]["windows_total"] == 4000 and d2["config"]["windows_per_rank"] == [2000, 2000]
+    assert d2["ranks"]["gathered_records_checked"] is True and d2["ranks"]["boundary_windows_checked_against_standalone_scans"] is True
+    # the halo: the two slabs together hold (window - step) sites more than the genome
+    assert 0 < d2["config"]["sites_read_per_step"] - 20000123 <= 5000 + 2 * 64
+    assert "byte-identical to stand-alone scans" in two.stderr
+    env = dict(os.environ, IMPOP_BENCH_FORCE_DIST="1")
+    env.pop("MASTER_PORT", None)
+    rc = subprocess.run([sys.executable] + base, capture_output=True, text=True, cwd=ROOT, env=env, timeout=900)
+    assert rc.returncode == 0, rc.stderr[-3000:]
+    d3 = _last_json(rc.stdout)
+    assert d3["ranks"]["backend"] == "rccl" and d3["ranks"]["gathered_records_checked"] is True

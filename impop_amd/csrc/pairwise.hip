@@ -420,8 +420,15 @@ __device__ __forceinline__ void gram_task_fp4(const uint32_t *__restrict__ rb, u
             mB &= plane_mask((U) + 1, 0);                                           \
         }                                                                           \
         const uint32_t soff = pair_soff((U) + 3);                                   \
-        FP4_PHASE(F, G, CUR, 1, mA, CUR, soff, false);                              \
-        FP4_PHASE(G, F, NXT, 0, mB, CUR, soff, true);                               \
+        if (IMPOP_GRAM_ABLATE & 4) { /* timing-only: loads and expansion VALU both run, but the expansions read a cell   \
+                                        that is never reloaded: no wait on load data anywhere in the loop */            \
+            Cell &ldc = (&(CUR) == &C0) ? C1 : (CUR);                               \
+            FP4_PHASE(F, G, C0, 1, mA, ldc, soff, false);                           \
+            FP4_PHASE(G, F, C0, 0, mB, ldc, soff, true);                            \
+        } else {                                                                    \
+            FP4_PHASE(F, G, CUR, 1, mA, CUR, soff, false);                          \
+            FP4_PHASE(G, F, NXT, 0, mB, CUR, soff, true);                           \
+        }                                                                           \
     } while (0)
         do {  // once, or once per used weight plane (a plain bottom-tested loop: more exits make the compiler shuffle the accumulators)
         if (wp.planes) P = wp.planes + (uint64_t)kcur * wp.stride + 2 * cell0;
@@ -468,6 +475,10 @@ __device__ __forceinline__ void gram_task_fp4(const uint32_t *__restrict__ rb, u
                 FP4_PAIR(C1, C2, u + 1);
                 FP4_PAIR(C2, C0, u + 2);
             }
+#if IMPOP_GRAM_ABLATE & 4
+#pragma unroll
+            for (int g = 0; g < 3; ++g) asm volatile("" ::"v"(C1.a[g]), "v"(C2.a[g]), "v"(C1.b[g]), "v"(C2.b[g]));
+#endif
         }
         asm volatile("s_nop 15\n\ts_nop 15");  // last MFMA results -> the VALU conversions / doublings below
         plane_left &= ~(1u << kcur);

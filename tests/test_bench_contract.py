@@ -92,7 +92,7 @@ def test_bench_config4_sharded_sliding_windows():
     assert one.returncode == 0, one.stderr[-3000:]
     d1 = _last_json(one.stdout)
     assert d1["scaling"] == "strong" and d1["n_gpus"] == 1 and "configs[3]" in d1["config"]["workload"]
-    assert d1["config"]["windows_total"] == 4000 and d1["config"]["window_sites"] == 10000 and d1["config"]["step_sites"] == 5000
+    assert d1["config"]["windows_total"] == 4001 and d1["config"]["window_sites"] == 10000 and d1["config"]["step_sites"] == 5000  # the last one clipped
     # every site is read once although every site lies in two windows
     assert abs(d1["config"]["sites_read_per_step"] - 20000123) < 64 * 2
     with socket.socket() as s:
@@ -103,7 +103,7 @@ def test_bench_config4_sharded_sliding_windows():
                           "--master-port", str(port)] + base + ["--gpus", "2"], capture_output=True, text=True, cwd=ROOT, env=env, timeout=900)
     assert two.returncode == 0, two.stderr[-3000:]
     d2 = _last_json(two.stdout)
-    assert d2["n_gpus"] == 2 and d2["config"]["windows_total"] == 4000 and d2["config"]["windows_per_rank"] == [2000, 2000]
+    assert d2["n_gpus"] == 2 and d2["config"]["windows_total"] == 4001 and d2["config"]["windows_per_rank"] == [2001, 2000]
     assert d2["ranks"]["gathered_records_checked"] is True and d2["ranks"]["boundary_windows_checked_against_standalone_scans"] is True
     # the halo: the two slabs together hold (window - step) sites more than the genome
     assert 0 < d2["config"]["sites_read_per_step"] - 20000123 <= 5000 + 2 * 64

@@ -258,6 +258,12 @@ struct GramPlanes {          // bit planes of the site weights (weight_planes_ke
     uint32_t bits;           // planes with any set bit
 };
 constexpr uint32_t FP4_MAX_SLICE_PAIRS = (1u << 24) / 128;  // fp32 accumulators stay exact integers
+#ifndef IMPOP_GRAM_RING
+#define IMPOP_GRAM_RING 1  // 1: operands prefetched through a per-wave LDS ring (shipped); 0: straight into registers (A/B builds)
+#endif
+constexpr uint32_t RING_SLOT = 6 * 1024;  // one quad: 6 row groups x (4 cells x 32 rows x 8 B)
+constexpr uint32_t RING_SLOTS = 3;
+constexpr uint32_t RING_BYTES = RING_SLOT * RING_SLOTS;  // per wave: 18 KB; 4 waves x 2 workgroups = 144 of a CU's 160 KB
 
 __device__ __forceinline__ i32x4 fp4_planes(uint32_t x) {
     i32x4 f;
@@ -276,9 +282,11 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 template <bool DIAG>
 __device__ __forceinline__ void gram_task_fp4(const uint32_t *__restrict__ rb, uint64_t nb_row, uint32_t ti, uint32_t tj,
                                               const GramWindow w, uint32_t ks, uint32_t ksplit, int32_t *__restrict__ o,
-                                              uint32_t ld, uint32_t shift, bool add, const GramPlanes wp) {
+                                              uint32_t ld, uint32_t shift, bool add, const GramPlanes wp,
+                                              uint32_t ring /* LDS byte address of this wave's operand ring (wave-uniform) */) {
     constexpr int NB = DIAG ? 0 : 3;
     constexpr int NM = DIAG ? 6 : 9;  // MFMAs per phase
+    constexpr int NL = DIAG ? 3 : 6;  // row groups = global loads per quad
     const uint32_t lane = threadIdx.x & 63, r32 = lane & 31, hi_half = lane >> 5;
     // Weighted sites in ONE task (wp.planes != nullptr): I = sum_k 2^k Gram(M & W_k) by Horner over the used bit planes of
     // the weights, highest first — the K loop below runs once per plane with the plane's words ANDed into the A-side mask,
@@ -350,6 +358,37 @@ __device__ __forceinline__ void gram_task_fp4(const uint32_t *__restrict__ rb, u
         auto pair_soff = [&](uint32_t u) -> uint32_t {  // clamp: never past the slice's last pair
             return ((u < uend ? u : uend - 1) - ubeg) * 512u;
         };
+        // ---- operand ring in LDS (IMPOP_GRAM_RING, the shipped path) --------------------------------------------------
+        // Measured on the direct-to-register version (tools/ablate_gram_fp4.sh): 7.9 ms per 4096 windows, of which
+        // 1.1 ms is waiting for load data — three cell buffers in registers are a prefetch distance of ~2.5 pairs (1.4 us), less
+        // than a loaded HBM / L2-miss latency, and there is no register left for a fourth (2 waves per SIMD x 144 accumulators).
+        // So the prefetch buffer moves to LDS: `buffer_load_dwordx4 ... lds` writes 1 KB per wave instruction — cells c..c+3 of a
+        // 32-row group = two pairs, a "quad" — straight into this wave's private ring of RING_SLOTS quads (no VGPR, no barrier:
+        // nobody else reads the ring), 2-3 quads = 8-12 phases ahead of use, and a lane fetches its dword pair of the NEXT pair
+        // with one ds_read_b64 per row group one phase before the expansion needs it.  The ds_reads are volatile asm (the compiler
+        // must not put `vmcnt(0)` in front of LDS reads it would see aliasing the DMA); the waits are explicit:
+        //   vmcnt(NL)  before the first ds_read of a quad: everything but the newest quad's NL loads has landed (loads return in
+        //              order; the queue pop's atomic drained the previous task's stores),
+        //   lgkmcnt(0) before the first expansion that reads a ds_read's destination.
+        const uint32_t nquad = (uend - ubeg + 1) >> 1;  // quad j = pairs ubeg + 2j, ubeg + 2j + 1
+        auto quad_soff = [&](uint32_t j) -> uint32_t { return (j < nquad ? j : nquad - 1) * 1024u; };  // clamped like pair_soff
+        const uint32_t dma_voff = lane * 16;
+        typedef __attribute__((address_space(3))) void *lds_ptr_t;
+        auto dma_one = [&](int i, uint32_t slot_lds, uint32_t soff) {  // i = 0..2: A groups, 3..5: B groups; slot_lds wave-uniform
+            if (i < 3) __builtin_amdgcn_raw_ptr_buffer_load_lds(rA[i], (lds_ptr_t)(uintptr_t)(slot_lds + i * 1024), 16, dma_voff, soff, 0, 0);
+            else __builtin_amdgcn_raw_ptr_buffer_load_lds(rB[i - 3], (lds_ptr_t)(uintptr_t)(slot_lds + i * 1024), 16, dma_voff, soff, 0, 0);
+        };
+        const uint32_t lds_lane = ring + r32 * 8 + hi_half * 256;  // this lane's dword pair inside a 512-byte pair of a group
+#define DS_CELL(DST, VA, IMM) asm volatile("ds_read_b64 %0, %1 offset:" #IMM : "=v"(DST) : "v"(VA) : "memory")
+#define DS_ONE(C, I, VA)                          \
+    do {                                          \
+        if ((I) == 0) DS_CELL(C.a[0], VA, 0);     \
+        if ((I) == 1) DS_CELL(C.a[1], VA, 1024);  \
+        if ((I) == 2) DS_CELL(C.a[2], VA, 2048);  \
+        if ((I) == 3) DS_CELL(C.b[0], VA, 3072);  \
+        if ((I) == 4) DS_CELL(C.b[1], VA, 4096);  \
+        if ((I) == 5) DS_CELL(C.b[2], VA, 5120);  \
+    } while (0)
         // The phase is scheduled BY HAND in volatile inline asm: builtins let the compiler float the
         // expansion arithmetic across sched_barriers (it is not chained to them) and the MFMAs ended up
         // in runs of 3-9 with the VALU work in one lump behind them.  Volatile asm statements keep their
@@ -420,19 +459,84 @@ __device__ __forceinline__ void gram_task_fp4(const uint32_t *__restrict__ rb, u
             mB &= plane_mask((U) + 1, 0);                                           \
         }                                                                           \
         const uint32_t soff = pair_soff((U) + 3);                                   \
-        if (IMPOP_GRAM_ABLATE & 4) { /* timing-only: loads and expansion VALU both run, but the expansions read a cell   \
-                                        that is never reloaded: no wait on load data anywhere in the loop */            \
-            Cell &ldc = (&(CUR) == &C0) ? C1 : (CUR);                               \
-            FP4_PHASE(F, G, C0, 1, mA, ldc, soff, false);                           \
-            FP4_PHASE(G, F, C0, 0, mB, ldc, soff, true);                            \
-        } else {                                                                    \
-            FP4_PHASE(F, G, CUR, 1, mA, CUR, soff, false);                          \
-            FP4_PHASE(G, F, NXT, 0, mB, CUR, soff, true);                           \
+        FP4_PHASE(F, G, CUR, 1, mA, CUR, soff, false);                              \
+        FP4_PHASE(G, F, NXT, 0, mB, CUR, soff, true);                               \
+    } while (0)
+        // The ring version of a phase: MFMA i, then (first-half phases) nothing more than the expansion, (second-half phases)
+        // the ds_read of row group i of the pair after next into the cell the previous phase finished with; DMA_MODE 1 / 2
+        // issues the A / B row groups of the quad three ahead into the slot whose last ds_read has been waited for.
+#define FP4_PHASE_R(CURF, NXTF, SRC, D, M, DSC, VA, DO_DS, WAITS, DMA_MODE, SLOT_LDS, SOFF)                  \
+    do {                                                                                                  \
+        uint32_t xa0 = 0, xa1 = 0, xa2 = 0;                                                               \
+        _Pragma("unroll") for (int i = 0; i < NM; ++i) {                                                  \
+            const int a = DIAG ? (i < 3 ? 0 : i < 5 ? 1 : 2) : i / 3;                                     \
+            const int b = DIAG ? (i < 3 ? i : i < 5 ? i - 2 : 2) : i % 3;                                 \
+            if (DIAG) mfma_asm(acc[a][b], CURF.a[a], CURF.a[b]);                                          \
+            else mfma_asm(acc[a][b], CURF.a[a], CURF.b[b]);                                               \
+            if (i == 0 && (WAITS) == 1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                \
+            if (i == 0 && (WAITS) == 2 && DIAG) asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");  \
+            if (i == 0 && (WAITS) == 2 && !DIAG) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory"); \
+            if (DO_DS && i < NL) DS_ONE(DSC, i, VA);                                                      \
+            if (!(IMPOP_GRAM_ABLATE & 2) && (DMA_MODE) == 1 && i < 3) dma_one(i, SLOT_LDS, SOFF);         \
+            if (!(IMPOP_GRAM_ABLATE & 2) && (DMA_MODE) == 2 && i < NB) dma_one(3 + i, SLOT_LDS, SOFF);    \
+            if (IMPOP_GRAM_ABLATE & 1) continue; /* timing-only build: no expansion VALU */               \
+            if (DIAG) {                                                                                   \
+                if (i == 0) lo_masked(NXTF.a[0], xa0, D ? SRC.a[0].y : SRC.a[0].x, M);                    \
+                if (i == 1) hi_planes(NXTF.a[0], xa0);                                                    \
+                if (i == 2) lo_masked(NXTF.a[1], xa1, D ? SRC.a[1].y : SRC.a[1].x, M);                    \
+                if (i == 3) hi_planes(NXTF.a[1], xa1);                                                    \
+                if (i == 4) lo_masked(NXTF.a[2], xa2, D ? SRC.a[2].y : SRC.a[2].x, M);                    \
+                if (i == 5) hi_planes(NXTF.a[2], xa2);                                                    \
+            } else {                                                                                      \
+                if (i == 0) lo_masked(NXTF.a[0], xa0, D ? SRC.a[0].y : SRC.a[0].x, M);                    \
+                if (i == 1) { hi_planes(NXTF.a[0], xa0); lo_plain(NXTF.b[0], D ? SRC.b[0].y : SRC.b[0].x); } \
+                if (i == 2) hi_planes(NXTF.b[0], D ? SRC.b[0].y : SRC.b[0].x);                            \
+                if (i == 3) lo_masked(NXTF.a[1], xa1, D ? SRC.a[1].y : SRC.a[1].x, M);                    \
+                if (i == 4) { hi_planes(NXTF.a[1], xa1); lo_plain(NXTF.b[1], D ? SRC.b[1].y : SRC.b[1].x); } \
+                if (i == 5) hi_planes(NXTF.b[1], D ? SRC.b[1].y : SRC.b[1].x);                            \
+                if (i == 6) lo_masked(NXTF.a[2], xa2, D ? SRC.a[2].y : SRC.a[2].x, M);                    \
+                if (i == 7) { hi_planes(NXTF.a[2], xa2); lo_plain(NXTF.b[2], D ? SRC.b[2].y : SRC.b[2].x); } \
+                if (i == 8) hi_planes(NXTF.b[2], D ? SRC.b[2].y : SRC.b[2].x);                            \
+            }                                                                                             \
+        }                                                                                                 \
+    } while (0)
+        // pair U lives in CUR (dword 0 already expanded in F), pair U+1 in NXT; the second phase refills CUR with pair U+2 from
+        // the ring (address VA).  WAITS 2 on the first pair of a quad (the quad it reads from must have landed), 1 on the second.
+#define FP4_PAIR_R(CUR, NXT, U, VA, WAITS, DMA1, DMA2, SLOT_LDS, SOFF)                \
+    do {                                                                            \
+        uint32_t mA = 0xFFFFFFFFu, mB = 0xFFFFFFFFu;                                \
+        if (!(4 * (U) + 1 > f && 4 * (U) + 6 < l && (U) + 1 < uend)) {              \
+            asm volatile("");                                                       \
+            mA = lane_mask((U), 1);                                                 \
+            mB = lane_mask((U) + 1, 0);                                             \
         }                                                                           \
+        if (P) {                                                                    \
+            mA &= plane_mask((U), 1);                                               \
+            mB &= plane_mask((U) + 1, 0);                                           \
+        }                                                                           \
+        FP4_PHASE_R(F, G, CUR, 1, mA, CUR, VA, false, 0, DMA1, SLOT_LDS, SOFF);     \
+        FP4_PHASE_R(G, F, NXT, 0, mB, CUR, VA, true, WAITS, DMA2, SLOT_LDS, SOFF);  \
     } while (0)
         do {  // once, or once per used weight plane (a plain bottom-tested loop: more exits make the compiler shuffle the accumulators)
         if (wp.planes) P = wp.planes + (uint64_t)kcur * wp.stride + 2 * cell0;
         if (ubeg < uend) {
+#if IMPOP_GRAM_RING
+            Cell C0, C1;
+            Frag F, G;
+#pragma unroll
+            for (int j = 0; j < (int)RING_SLOTS; ++j)  // quads 0 .. RING_SLOTS-1 on their way
+#pragma unroll
+                for (int i = 0; i < NL; ++i) dma_one(i < 3 ? i : i, ring + j * RING_SLOT, quad_soff(j));
+            if (DIAG) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");  // quad 0 has landed (RING_SLOTS - 1 quads may still fly)
+            else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+            static_assert(RING_SLOTS == 3, "the vmcnt immediates above assume three slots");
+            {
+                const uint32_t va0 = lds_lane, va1 = lds_lane + 512;
+#pragma unroll
+                for (int i = 0; i < NL; ++i) { DS_ONE(C0, i, va0); DS_ONE(C1, i, va1); }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
+#else
             Cell C0, C1, C2;
             Frag F, G;
 #pragma unroll
@@ -441,6 +545,7 @@ __device__ __forceinline__ void gram_task_fp4(const uint32_t *__restrict__ rb, u
                 load_one(C1, i, pair_soff(ubeg + 1));
                 load_one(C2, i, pair_soff(ubeg + 2));
             }
+#endif
             {
                 const uint32_t m0 = lane_mask(ubeg, 0) & (P ? plane_mask(ubeg, 0) : 0xFFFFFFFFu);
                 uint32_t xm;
@@ -470,14 +575,26 @@ __device__ __forceinline__ void gram_task_fp4(const uint32_t *__restrict__ rb, u
             }
             // no early exit (extra loop exits make the compiler merge 144 accumulators and spill): a slice
             // whose length is not a multiple of 3 pairs runs up to two fully masked pairs
+#if IMPOP_GRAM_RING
+            // one quad per iteration: its two pairs sit in C0 / C1; quad q + 1 is read out of slot (q + 1) % 3 into the cells
+            // as they fall free, quad q + 3 is sent after into slot q % 3 (fully read and waited for one iteration ago)
+            uint32_t slot = 0, qj = 0;  // slot of quad q (uniform), quad index relative to the slice
+            for (uint32_t u = ubeg; u < uend; u += 2) {
+                const uint32_t nslot = slot == RING_SLOTS - 1 ? 0 : slot + 1;
+                const uint32_t va = lds_lane + nslot * RING_SLOT;
+                const uint32_t slot_lds = ring + slot * RING_SLOT, soff = quad_soff(qj + RING_SLOTS);
+                FP4_PAIR_R(C0, C1, u, va, 2, 0, 0, slot_lds, soff);
+                FP4_PAIR_R(C1, C0, u + 1, va + 512, 1, 1, 2, slot_lds, soff);
+                slot = nslot;
+                ++qj;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the cells' last (unused) refills, before the registers are reused
+#else
             for (uint32_t u = ubeg; u < uend; u += 3) {
                 FP4_PAIR(C0, C1, u);
                 FP4_PAIR(C1, C2, u + 1);
                 FP4_PAIR(C2, C0, u + 2);
             }
-#if IMPOP_GRAM_ABLATE & 4
-#pragma unroll
-            for (int g = 0; g < 3; ++g) asm volatile("" ::"v"(C1.a[g]), "v"(C2.a[g]), "v"(C1.b[g]), "v"(C2.b[g]));
 #endif
         }
         asm volatile("s_nop 15\n\ts_nop 15");  // last MFMA results -> the VALU conversions / doublings below
@@ -496,6 +613,10 @@ __device__ __forceinline__ void gram_task_fp4(const uint32_t *__restrict__ rb, u
         } while (plane_left);
 #undef FP4_PAIR
 #undef FP4_PHASE
+#undef FP4_PAIR_R
+#undef FP4_PHASE_R
+#undef DS_ONE
+#undef DS_CELL
     }
     if (wp.planes) shift += kcur;  // Horner stopped at the lowest used plane (an empty window never started: its zeros shift to zero)
 #pragma unroll
@@ -515,12 +636,15 @@ __device__ __forceinline__ void gram_task_fp4(const uint32_t *__restrict__ rb, u
         }
 }
 
-// Persistent FP4 Gram kernel: same task queues as gram_mfma_kernel below, no LDS at all.
+// Persistent FP4 Gram kernel: same task queues as gram_mfma_kernel below; LDS only as each wave's private operand ring.
 __global__ __launch_bounds__(256, 2) void gram_fp4_kernel(const uint32_t *__restrict__ rb, uint64_t nb_row, uint32_t n_tiles,
                                                           uint32_t tasks_per_win, uint32_t n_win, uint32_t ksplit,
                                                           const GramWindow *__restrict__ wins, int32_t *__restrict__ out,
                                                           uint32_t ld, uint64_t out_stride, uint32_t *__restrict__ queue_heads,
                                                           uint32_t shift, bool add, GramPlanes wp) {
+    extern __shared__ __attribute__((aligned(1024))) unsigned char gram_ring[];  // 4 waves x RING_BYTES (dynamic: > 64 KB)
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint32_t ring = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)gram_ring + wave * RING_BYTES;
     const uint32_t slots = tasks_per_win * ksplit;
     const bool by_window = n_win >= 8;
     const uint64_t total = (uint64_t)n_win * slots;
@@ -540,8 +664,8 @@ __global__ __launch_bounds__(256, 2) void gram_fp4_kernel(const uint32_t *__rest
             while (rem >= n_tiles - ti) { rem -= n_tiles - ti; ++ti; }
             const uint32_t tj = ti + rem;
             int32_t *o = out + (uint64_t)win * out_stride;
-            if (ti == tj) gram_task_fp4<true>(rb, nb_row, ti, tj, wins[win], ks, ksplit, o, ld, shift, add, wp);
-            else gram_task_fp4<false>(rb, nb_row, ti, tj, wins[win], ks, ksplit, o, ld, shift, add, wp);
+            if (ti == tj) gram_task_fp4<true>(rb, nb_row, ti, tj, wins[win], ks, ksplit, o, ld, shift, add, wp, ring);
+            else gram_task_fp4<false>(rb, nb_row, ti, tj, wins[win], ks, ksplit, o, ld, shift, add, wp, ring);
         }
     }
 }
@@ -673,8 +797,13 @@ static int launch_gram(impop_ctx *ctx, const impop_matrix *m, const uint32_t *d_
     const uint32_t grid = (uint32_t)std::max<uint64_t>(8, std::min<uint64_t>(2ull * n_cu, need_wg));
     GramPlanes wp{nullptr, 0, 0};
     if (fused_planes) wp = GramPlanes{m->d_wplanes, m->wplane_stride, m->wplane_bits};
+    {
+        static const hipError_t ring_attr = hipFuncSetAttribute((const void *)gram_fp4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                                (int)(4 * RING_BYTES));  // 72 KB per workgroup: above the 64 KB default
+        HIP_TRY(ring_attr);
+    }
     if (gram_use_fp4())
-        hipLaunchKernelGGL(gram_fp4_kernel, dim3(grid), dim3(256), 0, ctx->stream, d_rb, m->rb_nb, T, tasks_per_win, n_win,
+        hipLaunchKernelGGL(gram_fp4_kernel, dim3(grid), dim3(256), 4 * RING_BYTES, ctx->stream, d_rb, m->rb_nb, T, tasks_per_win, n_win,
                            ksplit, d_wins, d_out, m->n_hap_pad, (uint64_t)m->n_hap_pad * m->n_hap_pad, ctx->d_queue,
                            add_shift < 0 ? 0u : (uint32_t)add_shift, add_shift >= 0, wp);
     else

@@ -116,6 +116,9 @@ struct impop_matrix {
     uint32_t *d_rb = nullptr;
     uint64_t rb_nb = 0;         // cells per row group incl. 4 cells of slack (prefetch)
     uint32_t n_hap_pad = 0;     // rows padded to a multiple of 96 (zero rows; Gram tiles are 96 wide)
+    // RB32 in minor-allele polarity (layout.hip sb_to_hm_kernel): row phi_row (= n_hap, inside the padding) holds the set of
+    // complemented sites; 0xFFFFFFFF = stored as given (no padding row free: n_hap a multiple of 96; or IMPOP_NO_POLARITY=1)
+    uint32_t phi_row = 0xFFFFFFFFu;
     uint64_t rb_bytes = 0;
     // compacted matrix (impop_matrix_compact): only the sites variable among all haplotypes were kept;
     // pos[k] = original index of kept site k (host copy for window mapping), n_site_orig = original length
@@ -133,6 +136,7 @@ struct impop_matrix {
     // dropped sites that EVERY haplotype carries (c_s = n): each adds 1 to every I_ij, so the all-pairs path on the
     // variable sites alone plus this per-window count is exact (pairwise.hip)
     uint32_t *d_onesmap = nullptr;
+    uint64_t *d_pos = nullptr;  // compacted: device copy of `pos` (map_windows_device: window edges -> kept-site indices on the GPU)
     bool compact = false;
     uint64_t n_site_orig = 0;
     std::vector<uint64_t> pos;
@@ -159,6 +163,9 @@ int ensure_tajima_consts(impop_ctx *ctx, int64_t n);  // fills ctx->d_taj for n 
 // ranges (`mapped`), else `mapped` is a plain copy.  span() = the coordinate range windows must lie in.
 inline uint64_t matrix_span(const impop_matrix *m) { return m->compact ? m->n_site_orig : m->g.n_site; }
 void map_windows(const impop_matrix *m, const impop_window *windows, uint64_t n, std::vector<impop_window> &mapped);
+// the same on the device (one thread per window edge, binary search in the device copy of the positions): 8192 searches over
+// 87 MB of positions cost the host 0.55 ms per call — as long as the Gram launch they precede — and the GPU some 50 us
+int map_windows_device(impop_ctx *ctx, const impop_matrix *m, const impop_window *windows, uint64_t n, std::vector<impop_window> &mapped);
 // compacted matrices: index of the first kept site at or right of original coordinate s (= number of kept sites left of s)
 uint64_t pos_lower_bound(const impop_matrix *m, uint64_t s);
 constexpr unsigned POS_COARSE_SHIFT = 12;
@@ -167,6 +174,6 @@ constexpr unsigned POS_COARSE_SHIFT = 12;
 int launch_hm_to_sb(impop_ctx *ctx, const uint32_t *d_hm, uint64_t hm_stride, const SbGeom &g, uint32_t *d_sb);
 // rb_nb == 0: plain hap-major rows of hm_stride dwords; else RB32 addressing with rb_nb cells per row group
 int launch_sb_to_hm(impop_ctx *ctx, const uint32_t *d_sb, const SbGeom &g, uint64_t blk_begin, uint64_t blk_end,
-                    uint32_t *d_hm, uint64_t hm_stride, uint32_t n_rows, uint64_t rb_nb = 0);
+                    uint32_t *d_hm, uint64_t hm_stride, uint32_t n_rows, uint64_t rb_nb = 0, uint32_t phi_row = 0xFFFFFFFFu);
 
 }  // namespace impop

@@ -54,13 +54,27 @@ __global__ __launch_bounds__(256) void hm_to_sb_kernel(const uint32_t *__restric
 // ---- SB64 -> hap-major ---------------------------------------------------------------
 // One wave per block; lane = site.  The 64-site hap-major word of haplotype 32k+j is bit j of every site's dword k,
 // gathered by transposing the two 32 x 32 bit matrices a dword k forms over the wave's halves (below).
+// phi_row != 0xFFFFFFFF (RB32 operand of the all-pairs path only): MINOR-ALLELE POLARITY.  A site more than half of the n_hap
+// haplotypes carry is stored complemented, and the set of complemented sites is stored as one more row — row phi_row = n_hap, in
+// the padding up to the next multiple of 96 — so that the Gram kernel delivers, for free, what undoes it:
+//     I_ij = I'_ij + I'_pp - I'_ip - I'_jp      (p = phi_row; primes = the stored polarity; gram_unflip_kernel, pairwise.hip)
+// while the Hamming distance a_i + a_j - 2 I_ij — all the `match` identity needs — is the same in either polarity.  Why: the FP4
+// matrix cores are power-limited and their power depends on the operands (tools/micro/fp4_power_probe.hip: 4.0-4.5 PMAC/s sustained
+// at 50 % ones, 4.8-4.9 at 5 % or 0 %); a presence matrix is 50 % ones only by the accident of which allele was called 1.  Measured on
+// the bench matrix (ancestral polarity random): Gram 8.0 -> 7.0 ms per 4096 windows of 465 x 50 kb.
 __global__ __launch_bounds__(256) void sb_to_hm_kernel(const uint32_t *__restrict__ sb, uint32_t wps, uint32_t G,
                                                        uint32_t r, uint64_t blk_begin, uint64_t blk_end,
                                                        uint32_t *__restrict__ hm, uint64_t hm_stride,
-                                                       uint32_t n_rows, uint64_t rb_nb) {
+                                                       uint32_t n_rows, uint64_t rb_nb, uint32_t phi_row, uint32_t n_hap) {
     const uint32_t lane = threadIdx.x & 63;
     const uint64_t b = blk_begin + (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (b >= blk_end) return;  // wave-uniform
+    uint32_t flip = 0;  // all ones: this lane's site is stored complemented
+    if (phi_row != 0xFFFFFFFFu) {
+        uint32_t c = 0;
+        for (uint32_t k = 0; k < wps; ++k) c += (uint32_t)__popc(sb[sb_index(wps, G, r, b, lane, k)]);
+        flip = 2 * c > n_hap ? 0xFFFFFFFFu : 0u;
+    }
     // Dword k of site `lane` holds haplotypes 32k .. 32k+31: each half of the wave is a 32 x 32 bit matrix (site x haplotype)
     // to transpose.  Five rounds of swapping the off-diagonal s x s blocks of every 2s x 2s block with lane ^ s (s = 16 .. 1):
     // one cross-lane move + four bit operations per round, against 32 ballots per dword before (18.8 ms per 12 GB matrix;
@@ -80,6 +94,7 @@ __global__ __launch_bounds__(256) void sb_to_hm_kernel(const uint32_t *__restric
         } else {
             w = sb[sb_index(wps, G, r, b, lane, k)];
         }
+        if (flip) w ^= 32 * k + 32 <= n_hap ? 0xFFFFFFFFu : 32 * k < n_hap ? (1u << (n_hap - 32 * k)) - 1u : 0u;  // real haplotypes only
 #pragma unroll
         for (uint32_t s = 16; s != 0; s >>= 1) {
             const uint32_t M = s == 16 ? 0x0000FFFFu : s == 8 ? 0x00FF00FFu : s == 4 ? 0x0F0F0F0Fu : s == 2 ? 0x33333333u : 0x55555555u;
@@ -87,11 +102,19 @@ __global__ __launch_bounds__(256) void sb_to_hm_kernel(const uint32_t *__restric
             w = (lane & s) ? ((w & ~M) | ((o >> s) & M)) : ((w & M) | ((o & M) << s));
         }
         const uint32_t row = 32 * k + j;
-        if (row < n_rows) {
+        if (row < n_rows && row != phi_row) {
             const uint64_t d = 2 * (b - blk_begin);  // first of the two dwords of this 64-site block
             uint32_t *p = rb_nb ? hm + ((((uint64_t)(row >> 5) * rb_nb + (d >> 1)) * 32 + (row & 31)) * 2)
                                 : hm + (uint64_t)row * hm_stride + d;
             p[half] = w;
+        }
+    }
+    if (phi_row != 0xFFFFFFFFu) {  // the complemented sites of this block as the 64-site word of row phi_row
+        const uint64_t bal = __ballot(flip != 0);
+        if (j == 0) {
+            const uint64_t d = 2 * (b - blk_begin);
+            uint32_t *p = hm + ((((uint64_t)(phi_row >> 5) * rb_nb + (d >> 1)) * 32 + (phi_row & 31)) * 2);
+            p[half] = half ? (uint32_t)(bal >> 32) : (uint32_t)bal;
         }
     }
 }
@@ -122,12 +145,13 @@ int launch_hm_to_sb(impop_ctx *ctx, const uint32_t *d_hm, uint64_t hm_stride, co
 }
 
 int launch_sb_to_hm(impop_ctx *ctx, const uint32_t *d_sb, const SbGeom &g, uint64_t blk_begin, uint64_t blk_end,
-                    uint32_t *d_hm, uint64_t hm_stride, uint32_t n_rows, uint64_t rb_nb) {
+                    uint32_t *d_hm, uint64_t hm_stride, uint32_t n_rows, uint64_t rb_nb, uint32_t phi_row) {
     if (blk_end <= blk_begin) return IMPOP_OK;
+    REQUIRE(phi_row == 0xFFFFFFFFu || (rb_nb != 0 && phi_row == g.n_hap && phi_row < n_rows), "launch_sb_to_hm: bad phi_row");
     const uint64_t grid = (blk_end - blk_begin + 3) / 4;
     REQUIRE(grid < 0x7FFFFFFFull, "range too long for one launch");
     hipLaunchKernelGGL(sb_to_hm_kernel, dim3((uint32_t)grid), dim3(256), 0, ctx->stream, d_sb, g.wps, g.G, g.r, blk_begin,
-                       blk_end, d_hm, hm_stride, n_rows, rb_nb);
+                       blk_end, d_hm, hm_stride, n_rows, rb_nb, phi_row, g.n_hap);
     HIP_TRY(hipGetLastError());
     return IMPOP_OK;
 }
@@ -149,7 +173,11 @@ __global__ __launch_bounds__(256) void synth_sb_kernel(SynthDev p, const uint32_
     if (b >= n_block) return;
     const bool live = b * 64 + lane < n_site;
     const uint64_t s = site0 + b * 64 + lane;  // the generator is counter-based on the GLOBAL site index: a slab is a cut of the whole
+#ifdef IMPOP_SYNTH_ANC0  // experiment builds only (tools/): every ancestral allele 0 => a sparse matrix with the same pairwise distances
+    const uint32_t anc = 0u;
+#else
     const uint32_t anc = (synth_hash(p.seed, 1, s) & 1ull) ? 0xFFFFFFFFu : 0u;
+#endif
     uint32_t fl = 0;
     for (uint32_t f = 0; f < p.n_founder; ++f)
         if ((uint32_t)(synth_hash(p.seed, 2 + f, s) >> 32) < p.thr_founder) fl |= 1u << f;
@@ -174,6 +202,10 @@ static int alloc_matrix(impop_ctx *ctx, uint32_t n_hap, uint64_t n_site, bool wa
     m->g = make_geom(n_hap, n_site);
     m->device = ctx->device;
     m->n_hap_pad = (n_hap + 95) / 96 * 96;  // Gram tiles are 96 haplotypes wide (3 row groups of 32)
+    {   // minor-allele polarity of the all-pairs operand (sb_to_hm_kernel) needs one padding row for the set of complemented sites
+        static const bool off = [] { const char *e = getenv("IMPOP_NO_POLARITY"); return e && e[0] == '1'; }();
+        m->phi_row = (want_hm && !off && n_hap % 96 != 0 && n_hap <= 16384 /* gram_unflip_kernel's LDS */) ? n_hap : 0xFFFFFFFFu;
+    }
     m->sb_bytes = m->g.n_block * 64ull * m->g.wps * 4ull;
     // one extra block of slack so software-pipelined kernels may prefetch one block past the end
     hipError_t e = hipMalloc((void **)&m->d_sb, m->sb_bytes + 64ull * m->g.wps * 4ull + 256);
@@ -251,7 +283,7 @@ IMPOP_API int impop_matrix_upload(impop_ctx *ctx, const uint64_t *bits, uint32_t
     rc = launch_hm_to_sb(ctx, d_hm, hm_stride, m->g, m->d_sb);
     if (rc) return fail(rc);
     if (want_rb) {
-        rc = launch_sb_to_hm(ctx, m->d_sb, m->g, 0, m->g.n_block, m->d_rb, 0, m->n_hap_pad, m->rb_nb);
+        rc = launch_sb_to_hm(ctx, m->d_sb, m->g, 0, m->g.n_block, m->d_rb, 0, m->n_hap_pad, m->rb_nb, m->phi_row);
         if (rc) return fail(rc);
         rc = ensure_segmap(ctx, m);  // a matrix kept for the all-pairs path gets its site bitmap (S per window) right away
         if (rc) return fail(rc);
@@ -313,7 +345,7 @@ IMPOP_API int impop_matrix_synthetic_slab(impop_ctx *ctx, uint32_t n_hap, uint64
                            wps, m->g.G, m->g.r, m->g.n_block, n_site, site_begin, m->d_sb);
         if ((e = hipGetLastError()) != hipSuccess) return fail(hip_fail(e, "synth_sb_kernel", __FILE__, __LINE__));
         if (want_hm) {
-            rc = launch_sb_to_hm(ctx, m->d_sb, m->g, 0, m->g.n_block, m->d_rb, 0, m->n_hap_pad, m->rb_nb);
+            rc = launch_sb_to_hm(ctx, m->d_sb, m->g, 0, m->g.n_block, m->d_rb, 0, m->n_hap_pad, m->rb_nb, m->phi_row);
             if (rc) return fail(rc);
             rc = ensure_segmap(ctx, m);
             if (rc) return fail(rc);
@@ -453,6 +485,41 @@ __global__ __launch_bounds__(256) void gather_variable_kernel(const uint32_t *__
 // Two levels: a binary search over 10^7 positions (87 MB) misses the cache on nearly every step — 8192 window edges cost
 // 0.7-4 ms per call, as much as the Gram launch they precede; every 4096th position (a few thousand entries, cache
 // resident) narrows the search to one 32 KB run first.
+__global__ void map_edges_kernel(const uint64_t *__restrict__ pos, uint64_t n_pos, const impop_window *__restrict__ win, uint64_t n_win,
+                                 impop_window *__restrict__ out) {
+    const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= 2 * n_win) return;
+    const uint64_t key = (e & 1) ? win[e >> 1].site_end : win[e >> 1].site_begin;
+    uint64_t lo = 0, len = n_pos;  // first kept site at or right of `key` (= kept sites left of it)
+    while (len) {
+        const uint64_t half = len >> 1;
+        if (pos[lo + half] < key) { lo += half + 1; len -= half + 1; }
+        else len = half;
+    }
+    if (e & 1) out[e >> 1].site_end = lo;
+    else { out[e >> 1].site_begin = lo; out[e >> 1].seq_len = win[e >> 1].seq_len; }
+}
+
+int map_windows_device(impop_ctx *ctx, const impop_matrix *m, const impop_window *windows, uint64_t n, std::vector<impop_window> &mapped) {
+    if (!m->compact || !m->d_pos || n < 256) {  // few windows: the host search is quicker than a launch and two copies
+        map_windows(m, windows, n, mapped);
+        return IMPOP_OK;
+    }
+    REQUIRE((2 * n + 255) / 256 < 0x7FFFFFFFull, "map_windows_device: too many windows");
+    void *d = nullptr;
+    const int rc = ctx_aux(ctx, 0, 2 * n * sizeof(impop_window), &d);  // slot 0 (h-fst partials) is idle before the first launch of a call
+    if (rc) return rc;
+    impop_window *d_in = reinterpret_cast<impop_window *>(d), *d_out = d_in + n;
+    mapped.resize(n);
+    HIP_TRY(hipMemcpyAsync(d_in, windows, n * sizeof(impop_window), hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(map_edges_kernel, dim3((uint32_t)((2 * n + 255) / 256)), dim3(256), 0, ctx->stream, m->d_pos, (uint64_t)m->pos.size(),
+                       d_in, n, d_out);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(mapped.data(), d_out, n * sizeof(impop_window), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return IMPOP_OK;
+}
+
 uint64_t pos_lower_bound(const impop_matrix *m, uint64_t s) {
     const std::vector<uint64_t> &pos = m->pos, &co = m->pos_coarse;
     if (co.empty()) return (uint64_t)(std::lower_bound(pos.begin(), pos.end(), s) - pos.begin());
@@ -582,11 +649,11 @@ IMPOP_API int impop_matrix_compact(impop_ctx *ctx, const impop_matrix *in, impop
         if ((e = hipMemcpyAsync(m->pos.data(), d_pos, n_kept * 8, hipMemcpyDeviceToHost, ctx->stream)) != hipSuccess)
             return fail2(e, "hipMemcpyAsync(positions)");
         if (want_pairs) {
-            const int rc2 = launch_sb_to_hm(ctx, m->d_sb, m->g, 0, m->g.n_block, m->d_rb, 0, m->n_hap_pad, m->rb_nb);
+            const int rc2 = launch_sb_to_hm(ctx, m->d_sb, m->g, 0, m->g.n_block, m->d_rb, 0, m->n_hap_pad, m->rb_nb, m->phi_row);
             if (rc2) { hipFree(d_pos); return fail(rc2); }
         }
         if ((e = hipStreamSynchronize(ctx->stream)) != hipSuccess) return fail2(e, "hipStreamSynchronize");
-        hipFree(d_pos);
+        m->d_pos = d_pos;  // kept: window edges are mapped on the device (map_windows_device)
     }
     m->pos_coarse.clear();
     for (size_t k = 0; k < m->pos.size(); k += (size_t)1 << POS_COARSE_SHIFT) m->pos_coarse.push_back(m->pos[k]);
@@ -691,6 +758,7 @@ IMPOP_API int impop_matrix_free(impop_ctx *ctx, impop_matrix *m) {
     if (m->d_rb) hipFree(m->d_rb);
     if (m->d_wt) hipFree(m->d_wt);
     if (m->d_onesmap) hipFree(m->d_onesmap);
+    if (m->d_pos) hipFree(m->d_pos);
     matrix_drop_derived(m);
     delete m;
     return IMPOP_OK;

@@ -9,6 +9,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <chrono>
 #include <type_traits>
 #include <vector>
 
@@ -259,7 +260,10 @@ struct GramPlanes {          // bit planes of the site weights (weight_planes_ke
 };
 constexpr uint32_t FP4_MAX_SLICE_PAIRS = (1u << 24) / 128;  // fp32 accumulators stay exact integers
 #ifndef IMPOP_GRAM_RING
-#define IMPOP_GRAM_RING 1  // 1: operands prefetched through a per-wave LDS ring (shipped); 0: straight into registers (A/B builds)
+#define IMPOP_GRAM_RING 0  // 0: operands straight into three rotating register cell buffers (shipped); 1: prefetched through a
+                          // per-wave LDS ring, 2-3 quads ahead (A/B builds: tools/build_variants.py pairwise.hip ring1:-DIMPOP_GRAM_RING=1).
+                          // Measured equal (7.07 vs 6.99 ms per 4096 windows, profiles/r03_gram_experiments.txt): the kernel is not
+                          // waiting for its loads, so the simpler form without LDS ships.
 #endif
 constexpr uint32_t RING_SLOT = 6 * 1024;  // one quad: 6 row groups x (4 cells x 32 rows x 8 B)
 constexpr uint32_t RING_SLOTS = 3;
@@ -358,11 +362,10 @@ __device__ __forceinline__ void gram_task_fp4(const uint32_t *__restrict__ rb, u
         auto pair_soff = [&](uint32_t u) -> uint32_t {  // clamp: never past the slice's last pair
             return ((u < uend ? u : uend - 1) - ubeg) * 512u;
         };
-        // ---- operand ring in LDS (IMPOP_GRAM_RING, the shipped path) --------------------------------------------------
-        // Measured on the direct-to-register version (tools/ablate_gram_fp4.sh): 7.9 ms per 4096 windows, of which
-        // 1.1 ms is waiting for load data — three cell buffers in registers are a prefetch distance of ~2.5 pairs (1.4 us), less
-        // than a loaded HBM / L2-miss latency, and there is no register left for a fourth (2 waves per SIMD x 144 accumulators).
-        // So the prefetch buffer moves to LDS: `buffer_load_dwordx4 ... lds` writes 1 KB per wave instruction — cells c..c+3 of a
+        // ---- operand ring in LDS (IMPOP_GRAM_RING = 1, an A/B build; see the macro) -----------------------------------
+        // The hypothesis it tested: three cell buffers in registers are a prefetch distance of ~2.5 pairs (1.4 us), less than a
+        // loaded HBM / L2-miss latency, and there is no register left for a fourth (2 waves per SIMD x 144 accumulators) — so
+        // let the prefetch buffer live in LDS: `buffer_load_dwordx4 ... lds` writes 1 KB per wave instruction — cells c..c+3 of a
         // 32-row group = two pairs, a "quad" — straight into this wave's private ring of RING_SLOTS quads (no VGPR, no barrier:
         // nobody else reads the ring), 2-3 quads = 8-12 phases ahead of use, and a lane fetches its dword pair of the NEXT pair
         // with one ds_read_b64 per row group one phase before the expansion needs it.  The ds_reads are volatile asm (the compiler
@@ -721,6 +724,36 @@ __global__ __launch_bounds__(256, 2) void gram_mfma_kernel(const uint32_t *__res
     }
 }
 
+// The operand is stored in minor-allele polarity (layout.hip sb_to_hm_kernel; m->phi_row): the counts the Gram kernel wrote are
+// I'_ij of the stored bits, with row / column p = phi_row holding I'_ip = (complemented sites haplotype i is stored with a 1 at)
+// and I'_pp = the number of complemented sites (weights: their summed weights).  For a complemented site b = 1 - b', so
+//     I_ij = I'_ij + I'_pp - I'_ip - I'_jp          (i <= j < n; the diagonal a_i = I_ii likewise)
+// Exact integers.  Needed where I or a themselves matter — the `dice` identity, exported counts; the `match` identity and every
+// statistic built on it see only a_i + a_j - 2 I_ij, which is the same in both polarities, and skip this pass.
+// grid: (matrices, row chunks); dynamic LDS: n int32.
+__global__ __launch_bounds__(256) void gram_unflip_kernel(int32_t *__restrict__ g, uint32_t ld, uint64_t stride, uint32_t n, uint32_t phi) {
+    extern __shared__ int32_t unflip_t[];
+    int32_t *G = g + (uint64_t)blockIdx.x * stride;
+    for (uint32_t i = threadIdx.x; i < n; i += 256) unflip_t[i] = G[(uint64_t)i * ld + phi];
+    const int32_t P = G[(uint64_t)phi * ld + phi];
+    __syncthreads();
+    for (uint32_t i = blockIdx.y; i < n; i += gridDim.y) {
+        const int32_t ri = P - unflip_t[i];
+        int32_t *row = G + (uint64_t)i * ld;
+        for (uint32_t j = i + threadIdx.x; j < n; j += 256) row[j] += ri - unflip_t[j];  // column phi itself (j = n) stays as written
+    }
+}
+static int launch_gram_unflip(impop_ctx *ctx, const impop_matrix *m, int32_t *d_g, uint64_t n_mats) {
+    if (m->phi_row == 0xFFFFFFFFu || n_mats == 0) return IMPOP_OK;
+    const uint32_t n = m->g.n_hap, ld = m->n_hap_pad;
+    REQUIRE(n_mats < 0x7FFFFFFFull && (size_t)n * 4 <= 64 * 1024, "gram_unflip: too many matrices / haplotypes");
+    const uint32_t chunks = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(4096 / n_mats, 1), 64);
+    hipLaunchKernelGGL(gram_unflip_kernel, dim3((uint32_t)n_mats, chunks), dim3(256), (size_t)n * 4, ctx->stream, d_g, ld,
+                       (uint64_t)ld * ld, n, m->phi_row);
+    HIP_TRY(hipGetLastError());
+    return IMPOP_OK;
+}
+
 // mirror the upper tiles into the lower triangle (only for host export)
 __global__ void gram_symmetrize_kernel(int32_t *g, uint32_t ld) {
     const uint32_t i = blockIdx.y * blockDim.y + threadIdx.y, j = blockIdx.x * blockDim.x + threadIdx.x;
@@ -794,16 +827,19 @@ static int launch_gram(impop_ctx *ctx, const impop_matrix *m, const uint32_t *d_
     // persistent grid: two 256-thread workgroups per CU (64 KB of LDS each), never fewer than 8
     const uint32_t n_cu = (uint32_t)(ctx->n_cu > 0 ? ctx->n_cu : 256);
     const uint64_t need_wg = ((uint64_t)n_win * tasks_per_win * ksplit + 3) / 4;
-    const uint32_t grid = (uint32_t)std::max<uint64_t>(8, std::min<uint64_t>(2ull * n_cu, need_wg));
+    // IMPOP_GRAM_WG_PER_CU=1 (A/B runs): one workgroup = one wave per SIMD on every CU (the LDS request keeps a second one out)
+    static const uint32_t wg_per_cu = [] { const char *e = getenv("IMPOP_GRAM_WG_PER_CU"); return (e && e[0] == '1') ? 1u : 2u; }();
+    const uint32_t grid = (uint32_t)std::max<uint64_t>(8, std::min<uint64_t>((uint64_t)wg_per_cu * n_cu, need_wg));
+    const uint32_t ring_lds = wg_per_cu == 1 ? 100u * 1024u : (IMPOP_GRAM_RING ? 4 * RING_BYTES : 0u);
     GramPlanes wp{nullptr, 0, 0};
     if (fused_planes) wp = GramPlanes{m->d_wplanes, m->wplane_stride, m->wplane_bits};
     {
         static const hipError_t ring_attr = hipFuncSetAttribute((const void *)gram_fp4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                                (int)(4 * RING_BYTES));  // 72 KB per workgroup: above the 64 KB default
+                                                                (int)(100 * 1024));  // 72 KB per workgroup: above the 64 KB default
         HIP_TRY(ring_attr);
     }
     if (gram_use_fp4())
-        hipLaunchKernelGGL(gram_fp4_kernel, dim3(grid), dim3(256), 4 * RING_BYTES, ctx->stream, d_rb, m->rb_nb, T, tasks_per_win, n_win,
+        hipLaunchKernelGGL(gram_fp4_kernel, dim3(grid), dim3(256), ring_lds, ctx->stream, d_rb, m->rb_nb, T, tasks_per_win, n_win,
                            ksplit, d_wins, d_out, m->n_hap_pad, (uint64_t)m->n_hap_pad * m->n_hap_pad, ctx->d_queue,
                            add_shift < 0 ? 0u : (uint32_t)add_shift, add_shift >= 0, wp);
     else
@@ -1078,6 +1114,8 @@ IMPOP_API int impop_pairwise_counts(impop_ctx *ctx, const impop_matrix *m, uint6
     HIP_TRY(hipMemcpyAsync(d_w, &w, sizeof w, hipMemcpyHostToDevice, ctx->stream));
     rc = launch_gram_any(ctx, m, d_w, &w, 1, d_g, d_t, w.site_end - w.site_begin);
     if (rc) return rc;
+    rc = launch_gram_unflip(ctx, m, d_g, 1);  // exported counts / identities: the original polarity
+    if (rc) return rc;
     const GramWindow ow{site_begin, site_end};
     const uint32_t add_w = compact_weighted(m) ? ones_weight(m, site_begin, site_end) : 0u;
     if (m->compact) {  // + the dropped sites every haplotype carries (their count, or their summed weights)
@@ -1125,6 +1163,8 @@ IMPOP_API int impop_pairwise_identity(impop_ctx *ctx, const impop_matrix *m, uin
     HIP_TRY(hipMemcpyAsync(d_W, &W, 8, hipMemcpyHostToDevice, ctx->stream));
     rc = launch_gram_any(ctx, m, d_w, &w, 1, d_g, d_t, w.site_end - w.site_begin);
     if (rc) return rc;
+    rc = launch_gram_unflip(ctx, m, d_g, 1);  // exported counts / identities: the original polarity
+    if (rc) return rc;
     SimBatch b{};
     b.gram = d_g; b.stride = (uint64_t)ld * ld; b.ld = ld; b.n = n; b.W = d_W; b.kind = identity_kind; b.round_digits = -1;
     const GramWindow ow{site_begin, site_end};
@@ -1168,6 +1208,13 @@ IMPOP_API int impop_pairwise_scan(impop_ctx *ctx, const impop_matrix *m, const i
     // integer S / W of the same windows from the streaming scan
     impop_scan_params sp;
     sp.struct_size = sizeof sp; sp.d_pi_mode = params->d_pi_mode; sp.s_scope = params->s_scope; sp.tile_blocks = 0;
+    // IMPOP_TRACE=1: host-side phase times of this call on stderr (where a call's time goes when the kernels are short)
+    static const bool trace = [] { const char *e = getenv("IMPOP_TRACE"); return e && e[0] == '1'; }();
+    const auto t_enter = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        if (trace) fprintf(stderr, "[impop_pairwise_scan] %-22s +%.1f us\n", what,
+                           std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_enter).count());
+    };
     // s_scope 2: the caller does not need S / Tajima's D (pica2- or Fst-only output): skip the site scan
     const bool want_s = params->s_scope != 2;
     if (!want_s) sp.s_scope = 0;
@@ -1207,14 +1254,28 @@ IMPOP_API int impop_pairwise_scan(impop_ctx *ctx, const impop_matrix *m, const i
     // windows themselves.
     // compacted matrix: the contraction runs over the KEPT (variable) sites of each window; the dropped all-ones
     // sites come back as a per-window constant (SimBatch.add), the dropped all-zero sites contribute nothing
+    lap("masks");
     std::vector<impop_window> mw;
-    map_windows(m, windows, n_windows, mw);
+    rc = map_windows_device(ctx, m, windows, n_windows, mw);
+    if (rc) return fail(rc);
+    lap("map_windows");
     struct Cell { uint64_t b, e; };
     std::vector<Cell> cells;                                // all Gram cells, in site order when segmented
     std::vector<uint32_t> first(n_windows, 0), count(n_windows, 0);
     std::vector<uint64_t> ord(n_windows);
     for (uint64_t i = 0; i < n_windows; ++i) ord[i] = i;
-    {
+    // the usual window list — a BED tiling: sorted, no two windows overlapping — has nothing to share: its cells are the windows
+    // (one O(n) check instead of the sort + searches below, 0.15 ms of host time per 4096 windows while the GPU waits)
+    bool tiling = n_windows < 0xFFFFFFF0ull;
+    for (uint64_t i = 1; i < n_windows && tiling; ++i) tiling = mw[i].site_begin >= mw[i - 1].site_end && mw[i].site_end >= mw[i].site_begin;
+    if (tiling) {
+        cells.resize(n_windows);
+        for (uint64_t i = 0; i < n_windows; ++i) {
+            cells[i] = {mw[i].site_begin, mw[i].site_end};
+            first[i] = (uint32_t)i;
+            count[i] = 1;
+        }
+    } else {
         std::vector<uint64_t> cuts;
         uint64_t win_sites = 0;
         for (uint64_t i = 0; i < n_windows; ++i)
@@ -1279,6 +1340,7 @@ IMPOP_API int impop_pairwise_scan(impop_ctx *ctx, const impop_matrix *m, const i
         for (uint64_t i = 0; i < n_windows; ++i) heaviest = std::max(heaviest, window_W(m, windows[i].site_begin, windows[i].site_end));
         if (heaviest < GRAM_FUSED_WEIGHT_LIMIT) plane_buffer = false;
     }
+    lap("cells");
     const size_t gram_bytes = (size_t)ld * ld * 4;
     uint64_t cap = ((plane_buffer ? 2ull : 4ull) << 30) / gram_bytes;
     if (cap < 1) cap = 1;
@@ -1344,6 +1406,7 @@ IMPOP_API int impop_pairwise_scan(impop_ctx *ctx, const impop_matrix *m, const i
         if ((cells.size() + n_chunks - 1) / n_chunks + widest > cap) ++n_chunks;  // neighbours re-contract up to `widest` cells
         cell_limit = std::min<uint64_t>(cap, (cells.size() + n_chunks - 1) / n_chunks + widest);
     }
+    lap("scratch + scan_host");
     std::vector<char> hmeta(meta_bytes, 0);
     GramWindow *gw = reinterpret_cast<GramWindow *>(hmeta.data() + o_w), *swv = reinterpret_cast<GramWindow *>(hmeta.data() + o_sw),
                *owv = reinterpret_cast<GramWindow *>(hmeta.data() + o_ow);
@@ -1390,6 +1453,7 @@ IMPOP_API int impop_pairwise_scan(impop_ctx *ctx, const impop_matrix *m, const i
             swv[k] = {mw[wdx].site_begin, mw[wdx].site_end};
             owv[k] = {windows[wdx].site_begin, windows[wdx].site_end};
         }
+        lap("chunk metadata");
         PW_TRY(hipMemcpyAsync(d_meta, hmeta.data(), meta_bytes, hipMemcpyHostToDevice, ctx->stream));
         if (use_segmap) {
             hipLaunchKernelGGL(seg_count_kernel, dim3((uint32_t)((cnt + 3) / 4)), dim3(256), 0, ctx->stream, m->d_segmap, d_sw, cnt, d_s,
@@ -1399,6 +1463,10 @@ IMPOP_API int impop_pairwise_scan(impop_ctx *ctx, const impop_matrix *m, const i
         if (n_cells) {
             rc = launch_gram_any(ctx, m, d_w, gw, n_cells, d_g, d_gt, max_sites);
             if (rc) return fail(rc);
+            if (params->identity_kind != IMPOP_IDENTITY_MATCH) {  // `match` sees Hamming distances only: polarity-invariant
+                rc = launch_gram_unflip(ctx, m, d_g, n_cells);
+                if (rc) return fail(rc);
+            }
         }
         SimBatch b{};
         b.gram = d_g; b.stride = (uint64_t)ld * ld; b.ld = ld; b.n = n; b.W = d_W; b.kind = params->identity_kind;
@@ -1449,6 +1517,7 @@ IMPOP_API int impop_pairwise_scan(impop_ctx *ctx, const impop_matrix *m, const i
         hipLaunchKernelGGL(pairwise_finalize_kernel, dim3((uint32_t)((cnt + 63) / 64)), dim3(64), 0, ctx->stream, in, cnt,
                            want_s ? nP : 0u, params->d_pi_mode, want_s ? params->s_scope : 0, ctx->d_taj, d_o);
         PW_TRY(hipGetLastError());
+        lap("chunk launched");
         PW_TRY(hipMemcpyAsync(ov.data(), d_o, cnt * sizeof(impop_pairwise_stats), hipMemcpyDeviceToHost, ctx->stream));
         rc = ctx_err_fetch(ctx);
         if (rc) return fail(rc);
@@ -1457,6 +1526,7 @@ IMPOP_API int impop_pairwise_scan(impop_ctx *ctx, const impop_matrix *m, const i
         if (rc) return fail(rc);
         for (uint64_t k = 0; k < cnt; ++k) out_host[ord[base + k]] = ov[k];
         base += cnt;
+        lap("chunk done");
     }
 #undef PW_TRY
     if (plan) impop_scan_plan_destroy(plan);

@@ -874,7 +874,60 @@ __global__ __launch_bounds__(ST) void hfst_kernel(SimBatch batch, const uint8_t 
         }
         __syncthreads();
         const uint32_t nm = n_members;
-        for (uint32_t k = (tid >> 6) + (ST / 64) * blockIdx.y; k < nm; k += (ST / 64) * gridDim.y) {
+        const uint32_t k_first = (tid >> 6) + (ST / 64) * blockIdx.y, k_step = (ST / 64) * gridDim.y;
+        uint32_t k_rest = k_first;
+        if (n <= 512 && S.nseg == 1) {
+            // One Gram matrix per problem and at most two 256-column steps per row (the window-statistics shape): TWO member rows
+            // per round, their (up to) four 16-byte loads issued before the first is consumed.  Row by row, load by load this
+            // loop had ONE load in flight per wave: 60 rows x 2 loads x a memory latency each = ~220 us per workgroup, 0.66 ms per
+            // 4096 windows for 1.8 GB of counts (2.7 TB/s) — latency-bound, not bandwidth-bound.  (Four rows in flight were tried
+            // in round 2 and lost to their registers; two rows cost 8 more.)
+            const uint32_t c40 = 4 * lane, c41 = 4 * lane + 256;
+            const uint32_t cls40 = c40 < n ? *reinterpret_cast<const uint32_t *>(cls_l + c40) : 0u;
+            const uint32_t cls41 = c41 < n ? *reinterpret_cast<const uint32_t *>(cls_l + c41) : 0u;
+            const i32v4 z4 = {0, 0, 0, 0};
+            const i32v4 dg0 = c40 < n ? *reinterpret_cast<const i32v4 *>(diag_l + c40) : z4;
+            const i32v4 dg1 = c41 < n ? *reinterpret_cast<const i32v4 *>(diag_l + c41) : z4;
+            for (; k_rest < nm; k_rest += 2 * k_step) {
+                const uint32_t rA = rows_l[k_rest];
+                const bool two = k_rest + k_step < nm;
+                const uint32_t rB = two ? rows_l[k_rest + k_step] : rA;
+                const int32_t *gA = S.gram + (uint64_t)rA * S.ld, *gB = S.gram + (uint64_t)rB * S.ld;
+                i32v4 vA0 = z4, vA1 = z4, vB0 = z4, vB1 = z4;
+                if (c40 < n && c40 + 3 > rA) vA0 = *reinterpret_cast<const i32v4 *>(gA + c40);
+                if (c41 < n && c41 + 3 > rA) vA1 = *reinterpret_cast<const i32v4 *>(gA + c41);
+                if (two && c40 < n && c40 + 3 > rB) vB0 = *reinterpret_cast<const i32v4 *>(gB + c40);
+                if (two && c41 < n && c41 + 3 > rB) vB1 = *reinterpret_cast<const i32v4 *>(gB + c41);
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+                    if (half && !two) break;
+                    const uint32_t r = half ? rB : rA;
+                    const uint32_t cr = cls_l[r];
+                    const int64_t ar = S.diag[r];
+                    double same = 0.0, other = 0.0;
+#pragma unroll
+                    for (int ch = 0; ch < 2; ++ch) {
+                        const uint32_t c4 = ch ? c41 : c40;
+                        const i32v4 v = half ? (ch ? vB1 : vB0) : (ch ? vA1 : vA0);
+                        const uint32_t cls4 = ch ? cls41 : cls40;
+                        const i32v4 dg = ch ? dg1 : dg0;
+                        const int32_t iv[4] = {v.x, v.y, v.z, v.w}, dgv[4] = {dg.x, dg.y, dg.z, dg.w};
+#pragma unroll
+                        for (uint32_t e = 0; e < 4; ++e) {
+                            const uint32_t c = c4 + e;
+                            const uint32_t cc = (cls4 >> (8 * e)) & 0xFFu;
+                            const bool live = (c > r) & (c < n) & (cc != 0);
+                            const double d = 1 - sim_from_gram(S, live ? (int64_t)iv[e] + S.add : 0, live ? ar : 0, live ? (int64_t)dgv[e] : 0);
+                            same += (live & (cc == cr)) ? d : 0.0;
+                            other += (live & (cc != cr)) ? d : 0.0;
+                        }
+                    }
+                    if (cr == 1) accA += same; else accB += same;
+                    accX += other;
+                }
+            }
+        }
+        for (uint32_t k = k_rest; k < nm; k += k_step) {
             const uint32_t r = rows_l[k];
             const uint32_t cr = cls_l[r];
             const int64_t ar = S.diag[r];

@@ -725,6 +725,51 @@ def test_int8_gram_kernel_still_exact():
     assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stderr
 
 
+def test_minor_allele_polarity_of_the_operand_is_invisible():
+    """The all-pairs operand is stored in minor-allele polarity (sites most haplotypes carry are complemented, the set of such
+    sites is one more row of the Gram; gram_unflip_kernel restores I and a where they matter).  Nothing a caller can see may
+    depend on it: counts, both identities and the scan records of the default build must be byte-identical to a process run with
+    IMPOP_NO_POLARITY=1 — on a matrix with a random ancestral polarity (half the sites flipped), overlapping windows (segment
+    sums), a weighted matrix, a compacted one, and a haplotype count that leaves no padding row (96: stored as given)."""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    code = r"""
+import sys, hashlib
+import numpy as np
+import impop_amd
+ctx = impop_amd.Context(0)
+h = hashlib.sha256()
+rng = np.random.default_rng(11)
+for n, W in ((61, 1500), (96, 700), (200, 2100)):
+    anc = rng.integers(0, 2, size=W, dtype=np.uint8)
+    f = np.repeat(anc[None], 5, axis=0) ^ (rng.random((5, W)) < 0.02).astype(np.uint8)
+    m = f[rng.integers(0, 5, size=n)] ^ (rng.random((n, W)) < 0.003).astype(np.uint8)
+    inA = (np.arange(n) % 3 == 0).astype(np.uint8); inB = (np.arange(n) % 3 == 1).astype(np.uint8)
+    bm = ctx.upload_dense(m, keep_hap_major=True)
+    wins = [(0, W, W), (5, W // 2, 700), (W // 3, W - 7, 0), (W // 4, W // 2 + 100, 50000)]
+    for mat in (bm, bm.compact()):
+        for kind in ("match", "dice"):
+            for fm in ("direct", "grouped"):
+                r = mat.pairwise_scan(wins, None, inA, inB, kind=kind, threshold=0.99, round_digits=4, fst_method=fm)
+                h.update(r.tobytes())
+    h.update(bm.pairwise_counts(3, W - 1).tobytes())
+    h.update(bm.pairwise_identity(0, W, "dice").tobytes()); h.update(bm.pairwise_identity(10, W, "match").tobytes())
+    bm.set_site_weights(rng.integers(1, 40, size=W).astype(np.uint32))
+    h.update(bm.pairwise_counts(0, W).tobytes())
+    h.update(bm.pairwise_scan(wins[:2], None, inA, inB, kind="dice", threshold=0.98, round_digits=None).tobytes())
+print(h.hexdigest())
+"""
+    outs = []
+    for off in ("0", "1"):
+        env = dict(os.environ, IMPOP_NO_POLARITY=off, PYTHONPATH=ROOT)
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, cwd=ROOT, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(r.stdout.strip())
+    assert outs[0] == outs[1] and len(outs[0]) == 64
+
+
 def test_gram_exact_beyond_fp32_integer_range(ctx):
     """FP4 MFMAs accumulate in fp32, exact only below 2^24: a window longer than that is K-split so
     that every partial stays exact and the int32 sum is still I_ij to the last unit (all-ones rows:

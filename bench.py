@@ -498,10 +498,23 @@ def main():
                 sk.bind(("127.0.0.1", 0))
                 os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-        else:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
+        # RCCL prints a version banner to STDOUT when the communicator is built; stdout belongs to the ONE JSON line, so the
+        # file descriptor points at stderr until the first collective has gone through
+        sys.stdout.flush()
+        saved_stdout = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            if backend == "nccl":
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            else:
+                dist.init_process_group("gloo", rank=rank, world_size=world)
+            dist.barrier()
+            if backend == "nccl":
+                torch.cuda.synchronize(dev)
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved_stdout, 1)
+            os.close(saved_stdout)
 
     # ONE explicit stream carries everything: the scan kernels (the engine context is built on it), the
     # collective's pre-event (RCCL waits for the work that is on the CURRENT stream when the collective is

@@ -20,8 +20,8 @@ RANK_KEYS = ("backend", "kernel_ms_avg_min", "kernel_ms_avg_max", "kernel_ms_avg
 
 
 def _last_json(text):
-    lines = [ln for ln in text.strip().splitlines() if ln.startswith("{")]
-    assert len(lines) == 1, text  # exactly ONE JSON line on stdout
+    lines = [ln for ln in text.strip().splitlines() if ln.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), text  # stdout is exactly ONE JSON line (RCCL's banner goes to stderr)
     return json.loads(lines[0])
 
 

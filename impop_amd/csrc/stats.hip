@@ -856,6 +856,77 @@ __global__ __launch_bounds__(ST) void hfst_kernel(SimBatch batch, const uint8_t 
         // LDS word, so a pair costs a handful of branch-free instructions: Hamming distance -> memoised identity ->
         // masked adds into (same class, other class).  Pair counts are the class sizes' products — nothing to count.
         __shared__ uint32_t n_members, n_a, n_b;
+        if (n <= 512) {
+            // Up to 512 sequences (the window-statistics shape): a GATHER over the member columns.  The sweep below evaluates
+            // every 4-column slot of every member row — 240 rows x 512 columns = 123 k slots per 465-haplotype window for the
+            // 28.7 k pairs that count, ~60 instructions each, and that arithmetic (not memory: 0.62 ms per 4096 windows for
+            // 1.8 GB) was the kernel's time.  Here the two classes' members are listed in ascending order once; a wave takes a
+            // member row r and visits exactly the members right of it, class A then class B — which accumulator a visit feeds
+            // is then uniform per loop, no class masks, no dead columns — with all of a row's loads issued before the first
+            // is consumed.  Same pairs, same identities (sim_from_gram), another summation order (tolerance: INTEGRATION.md §4).
+            __shared__ uint16_t colA[512], colB[512], prefA[512], prefB[512];
+            if (tid < 64) {
+                uint32_t na = 0, nb = 0;
+                for (uint32_t i0 = 0; i0 < n; i0 += 64) {
+                    const uint32_t i = i0 + tid;
+                    const uint32_t cc = i < n ? cls_l[i] : 0u;
+                    const uint64_t balA = __ballot(cc == 1), balB = __ballot(cc == 2), below = (1ull << tid) - 1ull;
+                    const uint32_t pa = na + (uint32_t)__popcll(balA & below), pb = nb + (uint32_t)__popcll(balB & below);
+                    if (cc == 1) colA[pa] = (uint16_t)i;
+                    if (cc == 2) colB[pb] = (uint16_t)i;
+                    if (i < n) {  // members of the class at positions <= i: where the members RIGHT of i start in the list
+                        prefA[i] = (uint16_t)(pa + (cc == 1));
+                        prefB[i] = (uint16_t)(pb + (cc == 2));
+                    }
+                    na += (uint32_t)__popcll(balA);
+                    nb += (uint32_t)__popcll(balB);
+                }
+                if (tid == 0) { n_a = na; n_b = nb; n_members = na + nb; }
+            }
+            __syncthreads();
+            const uint32_t na = n_a, nb = n_b, nmem = n_members;
+            for (uint32_t k = tid >> 6; k < nmem; k += ST / 64) {
+                const uint32_t r = k < na ? colA[k] : colB[k - na];
+                const uint32_t cr = k < na ? 1u : 2u;
+                const int64_t ar = S.diag[r];
+                const int32_t *g = S.gram + (uint64_t)r * S.ld;
+                double toA = 0.0, toB = 0.0;
+                // the members right of r: list positions [s, cnt) of each class, 64 per step, four steps' loads in flight; the
+                // step counts are wave-uniform (scalar branches), only the last step of a class has idle lanes
+#pragma unroll
+                for (int cls = 0; cls < 2; ++cls) {
+                    const uint16_t *col = cls ? colB : colA;
+                    const uint32_t s0 = cls ? prefB[r] : prefA[r], cnt = cls ? nb : na;
+                    double to = 0.0;
+                    for (uint32_t p0 = s0; p0 < cnt; p0 += 256) {
+                        int32_t v[4];
+                        uint32_t c[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            v[u] = 0; c[u] = 0xFFFFu;
+                            if (p0 + 64u * u < cnt) {  // uniform
+                                const uint32_t kk = p0 + 64u * u + lane;
+                                if (kk < cnt) {
+                                    c[u] = col[kk];
+                                    for (uint32_t q = 0; q < S.nseg; ++q) v[u] += g[q * S.seg_stride + c[u]];
+                                }
+                            }
+                        }
+#pragma unroll
+                        for (int u = 0; u < 4; ++u)
+                            if (p0 + 64u * u < cnt && c[u] != 0xFFFFu)
+                                to += 1 - sim_from_gram(S, (int64_t)v[u] + S.add, ar, (int64_t)diag_l[c[u]]);
+                    }
+                    if (cls) toB = to; else toA = to;
+                }
+                if (cr == 1) { accA += toA; accX += toB; }
+                else { accB += toB; accX += toA; }
+            }
+            if (tid == 0) {
+                const uint64_t a_ = na, b_ = nb;
+                cA = a_ * (a_ - (a_ ? 1 : 0)) / 2; cB = b_ * (b_ - (b_ ? 1 : 0)) / 2; cX = a_ * b_;
+            }
+        } else {
         uint32_t *rows_l = reinterpret_cast<uint32_t *>(hf_lds + (((size_t)n4 * 5 + 15) & ~(size_t)15));  // member rows, ascending
         if (tid == 0) { n_members = 0; n_a = 0; n_b = 0; }
         __syncthreads();
@@ -874,60 +945,7 @@ __global__ __launch_bounds__(ST) void hfst_kernel(SimBatch batch, const uint8_t 
         }
         __syncthreads();
         const uint32_t nm = n_members;
-        const uint32_t k_first = (tid >> 6) + (ST / 64) * blockIdx.y, k_step = (ST / 64) * gridDim.y;
-        uint32_t k_rest = k_first;
-        if (n <= 512 && S.nseg == 1) {
-            // One Gram matrix per problem and at most two 256-column steps per row (the window-statistics shape): TWO member rows
-            // per round, their (up to) four 16-byte loads issued before the first is consumed.  Row by row, load by load this
-            // loop had ONE load in flight per wave: 60 rows x 2 loads x a memory latency each = ~220 us per workgroup, 0.66 ms per
-            // 4096 windows for 1.8 GB of counts (2.7 TB/s) — latency-bound, not bandwidth-bound.  (Four rows in flight were tried
-            // in round 2 and lost to their registers; two rows cost 8 more.)
-            const uint32_t c40 = 4 * lane, c41 = 4 * lane + 256;
-            const uint32_t cls40 = c40 < n ? *reinterpret_cast<const uint32_t *>(cls_l + c40) : 0u;
-            const uint32_t cls41 = c41 < n ? *reinterpret_cast<const uint32_t *>(cls_l + c41) : 0u;
-            const i32v4 z4 = {0, 0, 0, 0};
-            const i32v4 dg0 = c40 < n ? *reinterpret_cast<const i32v4 *>(diag_l + c40) : z4;
-            const i32v4 dg1 = c41 < n ? *reinterpret_cast<const i32v4 *>(diag_l + c41) : z4;
-            for (; k_rest < nm; k_rest += 2 * k_step) {
-                const uint32_t rA = rows_l[k_rest];
-                const bool two = k_rest + k_step < nm;
-                const uint32_t rB = two ? rows_l[k_rest + k_step] : rA;
-                const int32_t *gA = S.gram + (uint64_t)rA * S.ld, *gB = S.gram + (uint64_t)rB * S.ld;
-                i32v4 vA0 = z4, vA1 = z4, vB0 = z4, vB1 = z4;
-                if (c40 < n && c40 + 3 > rA) vA0 = *reinterpret_cast<const i32v4 *>(gA + c40);
-                if (c41 < n && c41 + 3 > rA) vA1 = *reinterpret_cast<const i32v4 *>(gA + c41);
-                if (two && c40 < n && c40 + 3 > rB) vB0 = *reinterpret_cast<const i32v4 *>(gB + c40);
-                if (two && c41 < n && c41 + 3 > rB) vB1 = *reinterpret_cast<const i32v4 *>(gB + c41);
-#pragma unroll
-                for (int half = 0; half < 2; ++half) {
-                    if (half && !two) break;
-                    const uint32_t r = half ? rB : rA;
-                    const uint32_t cr = cls_l[r];
-                    const int64_t ar = S.diag[r];
-                    double same = 0.0, other = 0.0;
-#pragma unroll
-                    for (int ch = 0; ch < 2; ++ch) {
-                        const uint32_t c4 = ch ? c41 : c40;
-                        const i32v4 v = half ? (ch ? vB1 : vB0) : (ch ? vA1 : vA0);
-                        const uint32_t cls4 = ch ? cls41 : cls40;
-                        const i32v4 dg = ch ? dg1 : dg0;
-                        const int32_t iv[4] = {v.x, v.y, v.z, v.w}, dgv[4] = {dg.x, dg.y, dg.z, dg.w};
-#pragma unroll
-                        for (uint32_t e = 0; e < 4; ++e) {
-                            const uint32_t c = c4 + e;
-                            const uint32_t cc = (cls4 >> (8 * e)) & 0xFFu;
-                            const bool live = (c > r) & (c < n) & (cc != 0);
-                            const double d = 1 - sim_from_gram(S, live ? (int64_t)iv[e] + S.add : 0, live ? ar : 0, live ? (int64_t)dgv[e] : 0);
-                            same += (live & (cc == cr)) ? d : 0.0;
-                            other += (live & (cc != cr)) ? d : 0.0;
-                        }
-                    }
-                    if (cr == 1) accA += same; else accB += same;
-                    accX += other;
-                }
-            }
-        }
-        for (uint32_t k = k_rest; k < nm; k += k_step) {
+        for (uint32_t k = (tid >> 6) + (ST / 64) * blockIdx.y; k < nm; k += (ST / 64) * gridDim.y) {
             const uint32_t r = rows_l[k];
             const uint32_t cr = cls_l[r];
             const int64_t ar = S.diag[r];
@@ -961,6 +979,7 @@ __global__ __launch_bounds__(ST) void hfst_kernel(SimBatch batch, const uint8_t 
         if (tid == 0) {
             const uint64_t na = n_a, nb = n_b;
             cA = na * (na - (na ? 1 : 0)) / 2; cB = nb * (nb - (nb ? 1 : 0)) / 2; cX = na * nb;
+        }
         }
     } else
     for (uint32_t r = tid >> 6; r < n; r += ST / 64) {

@@ -145,8 +145,10 @@ __device__ inline void join_blocks(const SimView &S, const JoinTest &T, const ui
             if (!live[u] || o + 3 <= cs[u] || o >= m) continue;  // no position of the quad is above the seed and in range
             if (T.vec) {
                 const int32_t *g = S.gram + (uint64_t)cs[u] * S.ld + o;  // o + 3 < ld: ld is a multiple of 4 and o < m <= ld
-                i32q v = *reinterpret_cast<const i32q *>(g);
-                for (uint32_t k = 1; k < S.nseg; ++k) v += *reinterpret_cast<const i32q *>(g + k * S.seg_stride);
+                // (a window without a single Gram segment — no sites, or on a compacted matrix no VARIABLE site, among overlapping
+                // windows — has nseg == 0: its counts are the constant alone, not the first segment of the chunk)
+                i32q v = i32q{0, 0, 0, 0};
+                for (uint32_t k = 0; k < S.nseg; ++k) v += *reinterpret_cast<const i32q *>(g + k * S.seg_stride);
                 iv[u] = v + (int32_t)S.add;
             } else {
                 const uint32_t es = idx ? idx[cs[u]] : cs[u];
@@ -608,8 +610,8 @@ __global__ __launch_bounds__(ST, 5) void pica2_kernel(SimBatch batch, const uint
                 for (uint32_t o4 = 256 * (rr >> 8) + 4 * lane; o4 < n_el; o4 += 256) {
                     if (o4 + 3 <= rr) continue;  // entirely left of the diagonal
                     const int32_t *gp = S.gram + (uint64_t)rr * S.ld + o4;  // o4 + 3 < ld: ld is a multiple of 4, o4 < n_el <= ld
-                    i32q v = *reinterpret_cast<const i32q *>(gp);
-                    for (uint32_t k = 1; k < S.nseg; ++k) v += *reinterpret_cast<const i32q *>(gp + k * S.seg_stride);
+                    i32q v = i32q{0, 0, 0, 0};  // nseg == 0: see join_blocks
+                    for (uint32_t k = 0; k < S.nseg; ++k) v += *reinterpret_cast<const i32q *>(gp + k * S.seg_stride);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const uint32_t o = o4 + e;

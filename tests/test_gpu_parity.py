@@ -928,6 +928,35 @@ def test_pairwise_scan_overlapping_windows_share_segments(ctx, oracle):
     bm.free()
 
 
+def test_window_without_a_gram_segment_among_overlapping_windows(ctx, oracle):
+    """Found by tools/soak_gram.py in round 3 (a bug since round 2's segment sharing): among OVERLAPPING windows a window that owns no
+    Gram segment — an empty site range, or on a compacted matrix a window without a single variable site — was given the first
+    segment of its chunk by the vectorised row readers (join tests of the grouping, Step 2 of pica2) instead of zero counts.  Such a
+    window must give the record it gives alone, and the compacted matrix the records of the full one."""
+    rng = np.random.default_rng(42)
+    n, W = 200, 6000
+    anc = rng.integers(0, 2, size=W, dtype=np.uint8)
+    f = np.repeat(anc[None], 6, axis=0) ^ (rng.random((6, W)) < 0.02).astype(np.uint8)
+    m = f[rng.integers(0, 6, size=n)] ^ (rng.random((n, W)) < 0.004).astype(np.uint8)
+    m[:, 2000:3500] = anc[None, 2000:3500]  # a stretch where all haplotypes agree: windows inside it have no variable site
+    inA = (np.arange(n) % 3 == 0).astype(np.uint8); inB = (np.arange(n) % 3 == 1).astype(np.uint8)
+    bm = ctx.upload_dense(m, keep_hap_major=True)
+    cm = bm.compact()
+    wins = [(0, 1500, 1500), (1000, 2600, 1600), (2100, 3400, 1300), (2500, 2500, 0), (2200, 3000, 800), (3000, 5000, 2000), (4000, 6000, 0)]
+    for kw in (dict(kind="match", threshold=1.0, round_digits=None), dict(kind="match", threshold=0.999, round_digits=5),
+               dict(kind="dice", threshold=0.99, round_digits=4), dict(kind="match", threshold=0.99, round_digits=None, fst_method="grouped")):
+        got = bm.pairwise_scan(wins, None, inA, inB, **kw)
+        for k, w in enumerate(wins):
+            one = bm.pairwise_scan([w], None, inA, inB, **kw)[0]
+            assert got[k].tobytes() == one.tobytes(), (kw, w)
+        assert cm.pairwise_scan(wins, None, inA, inB, **kw).tobytes() == got.tobytes(), kw
+        # the windows inside the stretch: every pair identical -> one group below a threshold of 1, pi = 0
+        inside = got[4]
+        assert int(inside["s_all"]) == 0 and float(inside["pi"]) == 0.0
+        assert int(inside["n_groups"]) == (n if kw["threshold"] >= 1.0 else 1)
+    cm.free(); bm.free()
+
+
 def test_weighted_sites_equal_bp_expanded_matrix(ctx, oracle):
     """impop_matrix_set_site_weights: one column per graph node with its length as weight must give the
     records of the bp-expanded matrix (the same integer sums, n_sites, pi, Fst ...), except that the

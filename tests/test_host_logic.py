@@ -155,3 +155,36 @@ def test_c_abi_shard_rule_equals_python_rule():
                 got = impop_amd.shard_windows_c(wins, world, r)
                 loc, s0, s1, (lo, hi) = shard_windows(wins, world, r)
                 assert got == (lo, hi - lo, s0, s1), (size, step, world, r, got)
+
+
+def test_config4_sharding_geometry_of_the_c_abi():
+    """BASELINE configs[3] (whole-genome 10 kb windows at a 5 kb step over N GPUs): what bench.py --config4 and
+    scripts/impop_scan.py --devices N ask of impop_shard_windows — host arithmetic, no GPU.  Contiguous window ranges (the first
+    n % shards ranges one window longer), every shard's slab = exactly the sites its windows touch, neighbouring slabs overlapping
+    by the (window - step) halo, the same ranges the torch.distributed path (impop_amd.distributed.shard_windows) cuts."""
+    import impop_amd
+    from impop_amd import engine
+    from impop_amd.distributed import shard_range, shard_windows
+    G, Wn, step = 20_000_123, 10_000, 5_000
+    wins = impop_amd.fixed_windows(G, Wn, step)
+    assert len(wins) == 4001 and int(wins[-1]["site_end"]) == G
+    for world in (1, 2, 3, 8):
+        nxt, covered = 0, 0
+        for r in range(world):
+            first, cnt, s0, s1 = engine.shard_windows_c(wins, world, r)
+            lo, hi = shard_range(len(wins), world, r)
+            assert (first, first + cnt) == (lo, hi) and first == nxt
+            nxt += cnt
+            assert s0 == int(wins[first]["site_begin"]) and s1 == int(wins[first + cnt - 1]["site_end"])
+            loc, t0, t1, _ = shard_windows(wins, world, r)
+            assert (t0, t1) == (s0, s1) and len(loc) == cnt and int(loc[0]["site_begin"]) == 0
+            if r:  # halo: this slab starts (window - step) sites before the previous one ends
+                assert prev_end - s0 == Wn - step
+            prev_end = s1
+            covered += s1 - s0
+        assert nxt == len(wins)
+        assert covered == G + (world - 1) * (Wn - step)  # every site once per slab, the halos twice
+    # more shards than windows: trailing shards are empty, nobody reads out of range
+    few = impop_amd.fixed_windows(25_000, Wn, step)
+    cnts = [engine.shard_windows_c(few, 8, r)[1] for r in range(8)]
+    assert sum(cnts) == len(few) and cnts == sorted(cnts, reverse=True)

@@ -283,15 +283,39 @@ __device__ __forceinline__ i32x8 fp4_operand(const i32x4 f) { return (i32x8){f.x
 typedef int i32x4v __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
+// A task = tile pair (ti, tj) of a CHAIN of `nchain` windows wins[win0], wins[win0 + wstep], ... (K-slice ks of ksplit; chains
+// only with ksplit == 1).  Why chains (round 3): on short windows — a compacted matrix, node-level matrices from a GFA, the
+// segments of sliding windows: 2-3 k columns = ~20 pairs = 6 us of MFMAs per task — a task spent more time in its latency chain
+// (queue ticket -> window bounds -> first operand loads, each a dependent global round trip) than on the matrix cores.  Inside a
+// chain the operand prefetch of the K loop's last iterations reaches into the NEXT window of the chain (same rows, another site
+// range: an soffset), and between the weight planes of one window it wraps around to the window's own first pairs, so that only
+// the first window of a chain waits for its first loads; one ticket and one scalar load of the bounds per chain link.
 template <bool DIAG>
 __device__ __forceinline__ void gram_task_fp4(const uint32_t *__restrict__ rb, uint64_t nb_row, uint32_t ti, uint32_t tj,
-                                              const GramWindow w, uint32_t ks, uint32_t ksplit, int32_t *__restrict__ o,
+                                              const GramWindow *__restrict__ wins, uint32_t win0, uint32_t wstep, uint32_t nchain,
+                                              uint32_t ks, uint32_t ksplit, int32_t *__restrict__ out, uint64_t out_stride,
                                               uint32_t ld, uint32_t shift, bool add, const GramPlanes wp,
                                               uint32_t ring /* LDS byte address of this wave's operand ring (wave-uniform) */) {
     constexpr int NB = DIAG ? 0 : 3;
     constexpr int NM = DIAG ? 6 : 9;  // MFMAs per phase
     constexpr int NL = DIAG ? 3 : 6;  // row groups = global loads per quad
     const uint32_t lane = threadIdx.x & 63, r32 = lane & 31, hi_half = lane >> 5;
+    struct Cell {
+        u32x2 a[3], b[3];
+    };
+    struct Frag {  // four FP4 operand dwords per 32-row group, kept as scalars so that asm can define them singly
+        uint32_t a[3][4], b[3][4];
+    };
+    Cell C0, C1, C2;          // raw cells of three consecutive pairs; across chain links they hold the prefetched first pairs
+    bool have_cells = false;  // wave-uniform: C0..C2 already hold pairs 0, 1, 2 of the window (plane pass) about to start
+    GramWindow w = wins[win0];
+    for (uint32_t link = 0; link < nchain; ++link) {
+    const uint32_t win = win0 + link * wstep;
+    const bool has_next = link + 1 < nchain;
+    const GramWindow wn = has_next ? wins[win + wstep] : w;  // next link's bounds, long before the prefetch needs them
+    int32_t *__restrict__ o = out + (uint64_t)win * out_stride;
+    uint32_t sh = shift;
+    bool stored = false;
     // Weighted sites in ONE task (wp.planes != nullptr): I = sum_k 2^k Gram(M & W_k) by Horner over the used bit planes of
     // the weights, highest first — the K loop below runs once per plane with the plane's words ANDed into the A-side mask,
     // the 144 accumulators are doubled in between (exact: powers of two, totals below 2^24) and written ONCE.  One launch
@@ -306,6 +330,30 @@ __device__ __forceinline__ void gram_task_fp4(const uint32_t *__restrict__ rb, u
         for (int b = 0; b < 3; ++b)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+    // entry (row, col) of the tile pair: row = ti*96 + 32a + (e&3) + 8(e>>2) + 4(lane>>5), col = tj*96 + 32b + (lane&31).  The address
+    // is a UNIFORM pointer per (a, b, e) (scalar arithmetic) plus ONE per-lane 32-bit offset: 144 per-lane 64-bit addresses would be
+    // hoisted out of the chain loop and spilled
+    const uint32_t lane_elem = (ti * GT + 4 * (lane >> 5)) * ld + tj * GT + r32;  // < ld^2 <= 2^32 (ld <= 65535 + padding)
+    auto store_blocks = [&](int a_from, int a_to) {  // the 32 x 32 blocks of accumulator rows [a_from, a_to) -> int32 counts
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int b = 0; b < 3; ++b) {
+                if (a < a_from || a >= a_to || (DIAG && b < a)) continue;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    int32_t *ob = o + ((uint64_t)(32 * a + (e & 3) + 8 * (e >> 2)) * ld + 32 * b);
+                    // weighted matrices: this launch is bit plane `shift` of the site weights, added into the other planes' sum
+                    const int32_t v = (int32_t)((uint32_t)(int32_t)acc[a][b][e] << sh);
+#if IMPOP_GRAM_ABLATE & 8  // timing-only build: results are not written (only one lane's worth, to keep the work alive)
+                    if (lane_elem == 0xFFFFFFFFu) ob[0] = v;
+                    continue;
+#endif
+                    if (ksplit == 1 && !add) ob[lane_elem] = v;
+                    else atomicAdd(&ob[lane_elem], v);
+                }
+            }
+    };
     if (w.site_end > w.site_begin) {
         const uint64_t cell0 = w.site_begin >> 6;
         const uint32_t ncell = (uint32_t)(((w.site_end + 63) >> 6) - cell0);
@@ -349,18 +397,35 @@ __device__ __forceinline__ void gram_task_fp4(const uint32_t *__restrict__ rb, u
             rB[g] = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(bB + g * g32b), 0, 0x7FFFFFFF, 0x00020000);
         }
         const uint32_t lane_off = r32 * 8 + hi_half * 256;  // row r32's dword pair inside the lane half's cell
-        struct Cell {
-            u32x2 a[3], b[3];
-        };
-        struct Frag {  // four FP4 operand dwords per 32-row group, kept as scalars so that asm can define them singly
-            uint32_t a[3][4], b[3][4];
-        };
         auto load_one = [&](Cell &C, int i, uint32_t soff) {  // i = 0..2: A groups, 3..5: B groups
             if (i < 3) C.a[i] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rA[i], lane_off, soff, 0));
             else C.b[i - 3] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rB[i - 3], lane_off, soff, 0));
         };
-        auto pair_soff = [&](uint32_t u) -> uint32_t {  // clamp: never past the slice's last pair
-            return ((u < uend ? u : uend - 1) - ubeg) * 512u;
+        // Where the pair loads of the K loop go.  The loop runs n3 = n rounded up to a multiple of 3 pairs (n = uend - ubeg; the
+        // filler pairs are fully masked) and loads three pairs ahead, so its last three loads are "pairs" n3, n3 + 1, n3 + 2 into
+        // C0, C1, C2: what the NEXT pass starts with — this window's first pairs again if another weight plane follows (`wrap`),
+        // else any valid address (the slice's last pair).  The next chain LINK's first pairs are loaded from the store epilogue
+        // instead (below): cells alive across all 144 accumulators' stores would not fit the 256 registers of a wave.
+        const uint32_t n_pairs = uend - ubeg, n3 = (n_pairs + 2) / 3 * 3;
+        bool nx_ok = false;
+        uint32_t nx_off = 0, nx_last = 0;  // byte offset of the next link's pair 0 from this slice's descriptor base; its last pair
+        if (has_next && ksplit == 1 && wn.site_end > wn.site_begin) {
+            const uint64_t cell0n = wn.site_begin >> 6;
+            const uint32_t ncelln = (uint32_t)(((wn.site_end + 63) >> 6) - cell0n);
+            if (cell0n >= cell0 && (cell0n - cell0) * 256 < 0x7FF00000ull) {
+                nx_ok = true;
+                nx_off = (uint32_t)((cell0n - cell0) * 256);
+                nx_last = ((ncelln + 1) >> 1) - 1;
+            }
+        }
+        bool wrap = false;  // set per plane pass: another plane of this window follows
+        auto pair_soff = [&](uint32_t u) -> uint32_t {
+            const uint32_t rel = u - ubeg;
+            if (rel < n_pairs) return rel * 512u;
+            if (rel < n3) return (n_pairs - 1) * 512u;  // masked filler pairs
+            const uint32_t j = rel - n3;                // 0, 1, 2
+            if (wrap) return (j < n_pairs ? j : n_pairs - 1) * 512u;
+            return (n_pairs - 1) * 512u;
         };
         // ---- operand ring in LDS (IMPOP_GRAM_RING = 1, an A/B build; see the macro) -----------------------------------
         // The hypothesis it tested: three cell buffers in registers are a prefetch distance of ~2.5 pairs (1.4 us), less than a
@@ -524,7 +589,6 @@ __device__ __forceinline__ void gram_task_fp4(const uint32_t *__restrict__ rb, u
         if (wp.planes) P = wp.planes + (uint64_t)kcur * wp.stride + 2 * cell0;
         if (ubeg < uend) {
 #if IMPOP_GRAM_RING
-            Cell C0, C1;
             Frag F, G;
 #pragma unroll
             for (int j = 0; j < (int)RING_SLOTS; ++j)  // quads 0 .. RING_SLOTS-1 on their way
@@ -540,14 +604,17 @@ __device__ __forceinline__ void gram_task_fp4(const uint32_t *__restrict__ rb, u
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             }
 #else
-            Cell C0, C1, C2;
             Frag F, G;
+            wrap = (plane_left & ~(1u << kcur)) != 0;
+            if (!have_cells) {  // first link of a chain (or nothing could be prefetched): wait for the first three pairs here
 #pragma unroll
-            for (int i = 0; i < (DIAG ? 3 : 6); ++i) {
-                load_one(C0, i, pair_soff(ubeg));
-                load_one(C1, i, pair_soff(ubeg + 1));
-                load_one(C2, i, pair_soff(ubeg + 2));
+                for (int i = 0; i < (DIAG ? 3 : 6); ++i) {
+                    load_one(C0, i, pair_soff(ubeg));
+                    load_one(C1, i, pair_soff(ubeg + 1));
+                    load_one(C2, i, pair_soff(ubeg + 2));
+                }
             }
+            have_cells = wrap;  // what the loop below leaves in C0..C2 (pair_soff)
 #endif
             {
                 const uint32_t m0 = lane_mask(ubeg, 0) & (P ? plane_mask(ubeg, 0) : 0xFFFFFFFFu);
@@ -614,6 +681,23 @@ __device__ __forceinline__ void gram_task_fp4(const uint32_t *__restrict__ rb, u
             }
         asm volatile("s_nop 7");  // VALU-written accumulators -> the next plane's first MFMA
         } while (plane_left);
+        // results out; the next chain link's first three pairs are requested once the first row of accumulator blocks has gone
+        // (its registers are free by then), so their latency runs under the other two thirds of the stores and the next link's set-up
+        if (wp.planes) sh += kcur;  // Horner stopped at the lowest used plane
+        store_blocks(0, 1);
+        __builtin_amdgcn_sched_barrier(0);  // the loads stay HERE: hoisted above the stores they would not fit the registers
+        if (nx_ok && !(IMPOP_GRAM_RING)) {
+#pragma unroll
+            for (int i = 0; i < (DIAG ? 3 : 6); ++i) {
+                load_one(C0, i, nx_off);
+                load_one(C1, i, nx_off + (1 < nx_last ? 1 : nx_last) * 512u);
+                load_one(C2, i, nx_off + (2 < nx_last ? 2 : nx_last) * 512u);
+            }
+            have_cells = true;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        store_blocks(1, 3);
+        stored = true;
 #undef FP4_PAIR
 #undef FP4_PHASE
 #undef FP4_PAIR_R
@@ -621,22 +705,9 @@ __device__ __forceinline__ void gram_task_fp4(const uint32_t *__restrict__ rb, u
 #undef DS_ONE
 #undef DS_CELL
     }
-    if (wp.planes) shift += kcur;  // Horner stopped at the lowest used plane (an empty window never started: its zeros shift to zero)
-#pragma unroll
-    for (int a = 0; a < 3; ++a)
-#pragma unroll
-        for (int b = 0; b < 3; ++b) {
-            if (DIAG && b < a) continue;
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const uint32_t row = ti * GT + 32 * a + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
-                const uint32_t col = tj * GT + 32 * b + r32;
-                // weighted matrices: this launch is bit plane `shift` of the site weights, added into the other planes' sum
-                const int32_t v = (int32_t)((uint32_t)(int32_t)acc[a][b][e] << shift);
-                if (ksplit == 1 && !add) o[(uint64_t)row * ld + col] = v;
-                else atomicAdd(&o[(uint64_t)row * ld + col], v);
-            }
-        }
+    if (!stored) store_blocks(0, 3);  // an empty window never started: zeros
+    w = wn;
+    }  // chain links
 }
 
 // Persistent FP4 Gram kernel: same task queues as gram_mfma_kernel below; LDS only as each wave's private operand ring.
@@ -644,31 +715,37 @@ __global__ __launch_bounds__(256, 2) void gram_fp4_kernel(const uint32_t *__rest
                                                           uint32_t tasks_per_win, uint32_t n_win, uint32_t ksplit,
                                                           const GramWindow *__restrict__ wins, int32_t *__restrict__ out,
                                                           uint32_t ld, uint64_t out_stride, uint32_t *__restrict__ queue_heads,
-                                                          uint32_t shift, bool add, GramPlanes wp) {
+                                                          uint32_t shift, bool add, GramPlanes wp, uint32_t chain) {
     extern __shared__ __attribute__((aligned(1024))) unsigned char gram_ring[];  // 4 waves x RING_BYTES (dynamic: > 64 KB)
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const uint32_t ring = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)gram_ring + wave * RING_BYTES;
     const uint32_t slots = tasks_per_win * ksplit;
     const bool by_window = n_win >= 8;
     const uint64_t total = (uint64_t)n_win * slots;
+    const uint32_t nc = (by_window && ksplit == 1 && chain > 1) ? chain : 1u;  // windows per ticket (gram_task_fp4: chains)
     for (uint32_t dq = 0; dq < 8; ++dq) {
         const uint32_t q = (blockIdx.x + dq) & 7;
-        const uint64_t q_len = by_window ? (uint64_t)((n_win + 7 - q) / 8) * slots : (total + 7 - q) / 8;
+        const uint32_t nwq = (n_win + 7 - q) / 8;  // windows of queue q: q, q + 8, ...
+        const uint64_t q_len = by_window ? (uint64_t)((nwq + nc - 1) / nc) * slots : (total + 7 - q) / 8;
         for (;;) {
             uint32_t k = 0;
             if ((threadIdx.x & 63) == 0) k = atomicAdd(&queue_heads[q], 1u);
             k = __builtin_amdgcn_readfirstlane(k);
             if (k >= q_len) break;
-            uint32_t win, t2;
-            if (by_window) { win = q + 8 * (k / slots); t2 = k % slots; }
-            else { const uint64_t i = q + 8ull * k; win = (uint32_t)(i / slots); t2 = (uint32_t)(i % slots); }
+            uint32_t win, t2, links = 1, wstep = 0;
+            if (by_window) {
+                const uint32_t wb = k / slots;  // ticket = (block of nc windows of this queue, tile pair)
+                t2 = k % slots;
+                win = q + 8 * (wb * nc);
+                links = nwq - wb * nc < nc ? nwq - wb * nc : nc;
+                wstep = 8;
+            } else { const uint64_t i = q + 8ull * k; win = (uint32_t)(i / slots); t2 = (uint32_t)(i % slots); }
             const uint32_t ks = t2 % ksplit;
             uint32_t rem = t2 / ksplit, ti = 0;
             while (rem >= n_tiles - ti) { rem -= n_tiles - ti; ++ti; }
             const uint32_t tj = ti + rem;
-            int32_t *o = out + (uint64_t)win * out_stride;
-            if (ti == tj) gram_task_fp4<true>(rb, nb_row, ti, tj, wins[win], ks, ksplit, o, ld, shift, add, wp, ring);
-            else gram_task_fp4<false>(rb, nb_row, ti, tj, wins[win], ks, ksplit, o, ld, shift, add, wp, ring);
+            if (ti == tj) gram_task_fp4<true>(rb, nb_row, ti, tj, wins, win, wstep, links, ks, ksplit, out, out_stride, ld, shift, add, wp, ring);
+            else gram_task_fp4<false>(rb, nb_row, ti, tj, wins, win, wstep, links, ks, ksplit, out, out_stride, ld, shift, add, wp, ring);
         }
     }
 }
@@ -833,6 +910,18 @@ static int launch_gram(impop_ctx *ctx, const impop_matrix *m, const uint32_t *d_
     const uint32_t ring_lds = wg_per_cu == 1 ? 100u * 1024u : (IMPOP_GRAM_RING ? 4 * RING_BYTES : 0u);
     GramPlanes wp{nullptr, 0, 0};
     if (fused_planes) wp = GramPlanes{m->d_wplanes, m->wplane_stride, m->wplane_bits};
+    // chains of windows per ticket (gram_task_fp4) where a task is short — at most 8192 columns = 64 pairs, 20 us of MFMAs — and
+    // there are enough tasks that every wave still draws >= 4 tickets (so the grid's last round stays small); IMPOP_GRAM_CHAIN=n overrides
+    uint32_t chain = 1;
+    const uint64_t planes_walked = fused_planes ? std::max<uint32_t>((uint32_t)__builtin_popcount(m->wplane_bits), 1u) : 1u;  // K passes per window
+    if (ksplit == 1 && n_win >= 8 && max_window_sites * planes_walked <= 8192) {
+        const uint64_t per_wave = (uint64_t)n_win * tasks_per_win / (8ull * n_cu);
+        chain = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(per_wave / 4, 1), 8);  // measured (tools/ab_chain.py): 1.90 / 1.79 / 1.75 ms
+    }                                                                                  // per 4096 compacted windows at 1 / 3 / 8 links
+    {
+        static const int forced = [] { const char *e = getenv("IMPOP_GRAM_CHAIN"); return e ? atoi(e) : 0; }();
+        if (forced > 0 && ksplit == 1) chain = (uint32_t)forced;
+    }
     {
         static const hipError_t ring_attr = hipFuncSetAttribute((const void *)gram_fp4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                                                 (int)(100 * 1024));  // 72 KB per workgroup: above the 64 KB default
@@ -841,7 +930,7 @@ static int launch_gram(impop_ctx *ctx, const impop_matrix *m, const uint32_t *d_
     if (gram_use_fp4())
         hipLaunchKernelGGL(gram_fp4_kernel, dim3(grid), dim3(256), ring_lds, ctx->stream, d_rb, m->rb_nb, T, tasks_per_win, n_win,
                            ksplit, d_wins, d_out, m->n_hap_pad, (uint64_t)m->n_hap_pad * m->n_hap_pad, ctx->d_queue,
-                           add_shift < 0 ? 0u : (uint32_t)add_shift, add_shift >= 0, wp);
+                           add_shift < 0 ? 0u : (uint32_t)add_shift, add_shift >= 0, wp, chain);
     else
         hipLaunchKernelGGL(gram_mfma_kernel, dim3(grid), dim3(256), 0, ctx->stream, d_rb, m->rb_nb, T, tasks_per_win, n_win,
                            ksplit, d_wins, d_out, m->n_hap_pad, (uint64_t)m->n_hap_pad * m->n_hap_pad, ctx->d_queue);

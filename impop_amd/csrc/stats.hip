@@ -246,19 +246,23 @@ __device__ inline uint32_t greedy_groups_bits(const uint64_t *__restrict__ adj, 
     constexpr int JU = 4;               // (candidate, 256-block) items in flight per wave
     constexpr uint32_t ROWS_S = GG_ROWS;
     __shared__ uint32_t cand[64];
-    __shared__ uint32_t sh_n, sh_G;
+    __shared__ uint32_t sh_n, sh_G, sh_B;
     if (m == 0) return 0;
     const uint32_t tid = threadIdx.x, lane = tid & 63;
     const uint32_t aw = bit_words(m), nh = aw / 4;
     uint64_t *rows = FROM_ADJ ? rows_big : rows_small;  // rows_big: m words (the caller's scratch)
-    uint32_t B;
+    // B = candidates per block.  It starts small (few groups: most candidates of a block are absorbed by an earlier seed of the
+    // same block, their join tests wasted) and DOUBLES, up to what the row words hold, after every block in which at least half the
+    // candidates opened a group — with hundreds of groups per window the blocks' fixed costs (two barriers, a round of memory
+    // latency, the serial resolution) were what the grouping's time went on: 29 blocks of 16 at 465 singleton groups, 9 when grown
+    uint32_t B, Bcap;
     if (FROM_ADJ) {
-        B = m / aw < 64 ? m / aw : 64;
+        B = Bcap = m / aw < 64 ? m / aw : 64;
     } else {
-        const uint32_t cap = ROWS_S / aw < 64 ? ROWS_S / aw : 64;      // >= 4: aw <= 128
+        Bcap = ROWS_S / aw < 64 ? ROWS_S / aw : 64;                    // >= 4: aw <= 128
         const uint32_t fill = (2 * (ST / 64) * JU + nh - 1) / nh;      // candidates whose blocks make two batches per wave
         B = fill < 4 ? 4 : fill;
-        if (B > cap) B = cap;
+        if (B > Bcap) B = Bcap;
     }
     const JoinTest T = FROM_ADJ ? JoinTest{false, false, 0, 0.0} : join_test(S, idx, thr);
     for (uint32_t i = tid; i < m; i += ST) { grp[i] = NONE; gsz[i] = 0; }
@@ -270,6 +274,7 @@ __device__ inline uint32_t greedy_groups_bits(const uint64_t *__restrict__ adj, 
     };
     uint64_t u0 = initial(lane), u1 = initial(lane + 64);  // the free set (wave 0's copy is the one that counts)
     uint32_t G = 0, h_first = 0;
+    if (tid == 0) { sh_G = 0; sh_B = B; }
     __syncthreads();
     // every block resolves at least one candidate: m blocks bound the loop whatever happens (a grid must drain).  Running
     // out of the bound means an invariant of this function broke: the device error word makes the CALL fail
@@ -346,7 +351,14 @@ __device__ inline uint32_t greedy_groups_bits(const uint64_t *__restrict__ adj, 
                     cs[u] = cand[b];
                     hs[u] = it - b * nh;
                 }
+#if defined(IMPOP_PICA2_ABLATE) && (IMPOP_PICA2_ABLATE & 2)  // timing-only build: no join tests (every candidate a singleton)
+#pragma unroll
+                for (int u = 0; u < JU; ++u)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) bits[u][j] = 0;
+#else
                 join_blocks<JU>(S, T, idx, m, cs, hs, live, bits);
+#endif
 #pragma unroll
                 for (int u = 0; u < JU; ++u)
                     if (lane < 4 && live[u]) rows[4 * (it0 + u) + lane] = pick4(bits[u], lane);
@@ -414,11 +426,16 @@ __device__ inline uint32_t greedy_groups_bits(const uint64_t *__restrict__ adj, 
                 }
                 pos = first + 1;
             }
-            if (lane == 0) sh_G = G;
+            if (lane == 0) {
+                const uint32_t opened = G - sh_G;  // groups this block opened (sh_G still holds the count before it)
+                sh_B = (2 * opened >= n && 2 * B <= Bcap) ? 2 * B : B;
+                sh_G = G;
+            }
             __builtin_amdgcn_s_setprio(0);
         }
         __syncthreads();
         G = __builtin_amdgcn_readfirstlane(sh_G);
+        B = __builtin_amdgcn_readfirstlane(sh_B);
     }
     if (!done && tid == 0 && S.err) atomicOr(S.err, DEV_ERR_GROUPING);
     return G;
@@ -563,6 +580,10 @@ __global__ __launch_bounds__(ST, 5) void pica2_kernel(SimBatch batch, const uint
             for (uint32_t i = tid; i < n_el; i += ST) group_of[prob * n_el + i] = grp[i];
         return;
     }
+#if defined(IMPOP_PICA2_ABLATE) && (IMPOP_PICA2_ABLATE & 1)  // timing-only build: Step 1 alone
+    if (tid == 0) { Pica2Out o; o.pi = 0; o.pi_site = 0; o.n_groups = G; o.pad = 0; o.sum_2pairs = 0; o.n_pairs = 0; out[prob] = o; }
+    return;
+#endif
     // Step 2-3 (pica2.py:118-154): sum over group pairs of 2*(1-sim(rep_i,rep_j))*f_i*f_j
     const double total = (double)n_el;
     uint32_t have = 0;

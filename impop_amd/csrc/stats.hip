@@ -157,6 +157,32 @@ __device__ inline void join_blocks(const SimView &S, const JoinTest &T, const ui
                     if (o + j > cs[u] && o + j < m) iv[u][j] = (int32_t)gram_at(S, es, idx ? idx[o + j] : o + j);  // positions ascend, so do the elements
             }
         }
+        if (T.vec && T.by_cutoff && S.diag && S.W < (1ull << 30)) {
+            // the common shape — rows read as quads at the positions themselves (no element list), `match` identity decided by the
+            // integer cutoff, diagonal in LDS, counts below 2^30: 32-bit arithmetic, the four diagonal entries of a quad as one
+            // 16-byte LDS read, the compare IS the ballot.  ~8 instructions per position instead of ~30 (64-bit Hamming arithmetic,
+            // a scalar LDS read and an element-list test per position): with hundreds of groups per window these tests were 1.3 ms of
+            // pica2's 3.1 ms per 4096 windows (profiles/r03_epilogue_kernels.txt)
+            const int32_t hcut = T.hstar > 0x7FFFFFFFll ? 0x7FFFFFFF : T.hstar < -1 ? -1 : (int32_t)T.hstar;
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const uint32_t o0 = 256 * hs[u] + 4 * lane;
+                const int32_t as = live[u] ? S.diag[cs[u] < m ? cs[u] : 0] : 0;
+                i32q dg = i32q{0, 0, 0, 0};
+                if (live[u] && o0 + 3 < m) dg = *reinterpret_cast<const i32q *>(S.diag + o0);  // o0 is a multiple of 4: aligned
+                else if (live[u]) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) dg[j] = o0 + j < m ? S.diag[o0 + j] : 0;
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const uint32_t o = o0 + j;
+                    const int32_t H = as + dg[j] - 2 * iv[u][j];
+                    bits[u][j] = __ballot(live[u] && o > cs[u] && o < m && H <= hcut);
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const uint32_t es = idx ? idx[cs[u] < m ? cs[u] : 0] : cs[u];
@@ -548,7 +574,8 @@ __global__ __launch_bounds__(ST, 5) void pica2_kernel(SimBatch batch, const uint
     const uint32_t tid = threadIdx.x;
     if (tid == 0) { sh_have = 0; sh_npairs = 0; }
     if (S.gram) {  // Gram problems: the diagonal a_i in LDS (behind the other arrays), else every identity costs three loads
-        int32_t *diag_l = reinterpret_cast<int32_t *>(gsz + n_el);
+        // 16-byte aligned (the launch's LDS size has 16 bytes of slack): join_blocks reads four diagonal entries at a time
+        int32_t *diag_l = reinterpret_cast<int32_t *>((reinterpret_cast<uintptr_t>(gsz + n_el) + 15) & ~(uintptr_t)15);
         for (uint32_t i = tid; i < batch.n; i += ST) diag_l[i] = (int32_t)gram_at(S, i, i);
         S.diag = diag_l;
         __syncthreads();
@@ -633,6 +660,27 @@ __global__ __launch_bounds__(ST, 5) void pica2_kernel(SimBatch batch, const uint
                     const int32_t *gp = S.gram + (uint64_t)rr * S.ld + o4;  // o4 + 3 < ld: ld is a multiple of 4, o4 < n_el <= ld
                     i32q v = i32q{0, 0, 0, 0};  // nseg == 0: see join_blocks
                     for (uint32_t k = 0; k < S.nseg; ++k) v += *reinterpret_cast<const i32q *>(gp + k * S.seg_stride);
+                    if (S.kind == IMPOP_IDENTITY_MATCH && S.tbl && S.W < (1ull << 30)) {
+                        // `match` with the memo filled (it is, from 48 groups on): the same values as the general form below, in
+                        // 32-bit arithmetic with the quad's four diagonal entries as one LDS read
+                        i32q dg = i32q{0, 0, 0, 0};
+                        if (o4 + 3 < n_el) dg = *reinterpret_cast<const i32q *>(S.diag + o4);
+                        else {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) dg[e] = o4 + e < n_el ? S.diag[o4 + e] : 0;
+                        }
+                        const int32_t ar32 = (int32_t)ar, add32 = (int32_t)S.add;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const uint32_t o = o4 + e;
+                            const bool live = o > rr && o < n_el;
+                            const int32_t H = live ? ar32 + dg[e] - 2 * (v[e] + add32) : 0;
+                            const double sv = (uint32_t)H < S.tbl_n ? S.tbl[H] : match_identity(S.W, (int64_t)H, S.round_digits);
+                            const double fj = live ? fpos[o] : 0.0;
+                            acc += 2 * ((1 - sv) * fi * fj);
+                        }
+                        continue;
+                    }
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const uint32_t o = o4 + e;

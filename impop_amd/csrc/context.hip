@@ -142,6 +142,7 @@ IMPOP_API int impop_ctx_destroy(impop_ctx *ctx) {
     if (ctx->d_taj) hipFree(ctx->d_taj);
     if (ctx->d_queue) hipFree(ctx->d_queue);
     if (ctx->d_err) hipFree(ctx->d_err);
+    for (auto &e : ctx->gram_events) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
     if (ctx->scratch) hipFree(ctx->scratch);
     for (void *a : ctx->d_aux)
         if (a) hipFree(a);
@@ -169,6 +170,30 @@ int ctx_err_result(impop_ctx *ctx, const char *fn) {
     return IMPOP_E_INTERNAL;
 }
 }  // namespace impop
+
+IMPOP_API int impop_ctx_gram_timing(impop_ctx *ctx, int enable) {
+    REQUIRE(ctx, "impop_ctx_gram_timing: ctx is NULL");
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    ctx->gram_timing = enable != 0;
+    ctx->gram_events_used = 0;
+    return IMPOP_OK;
+}
+
+IMPOP_API int impop_ctx_gram_elapsed(impop_ctx *ctx, double *total_ms, uint64_t *launches) {
+    REQUIRE(ctx, "impop_ctx_gram_elapsed: ctx is NULL");
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    double t = 0.0;
+    for (size_t i = 0; i < ctx->gram_events_used; ++i) {
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, ctx->gram_events[i].first, ctx->gram_events[i].second));
+        t += (double)ms;
+    }
+    if (total_ms) *total_ms = t;
+    if (launches) *launches = ctx->gram_events_used;
+    return IMPOP_OK;
+}
 
 IMPOP_API int impop_ctx_synchronize(impop_ctx *ctx) {
     REQUIRE(ctx, "impop_ctx_synchronize: ctx is NULL");

@@ -92,6 +92,10 @@ struct impop_ctx {
     // invariant fails (stats.hip: the grouping's progress bound), the call that launched them returns IMPOP_E_INTERNAL
     uint32_t *d_err = nullptr;
     uint32_t h_err = 0;
+    // impop_ctx_gram_timing: event pairs around the Gram launches of impop_pairwise_scan
+    bool gram_timing = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> gram_events;
+    size_t gram_events_used = 0;
     // side stream + fork/join events (created on first use): independent latency-bound epilogue kernels of the
     // all-pairs path run next to each other instead of one after the other
     hipStream_t side = nullptr;

@@ -1550,8 +1550,21 @@ IMPOP_API int impop_pairwise_scan(impop_ctx *ctx, const impop_matrix *m, const i
             PW_TRY(hipGetLastError());
         }
         if (n_cells) {
+            hipEvent_t ev1 = nullptr;
+            if (ctx->gram_timing) {  // impop_ctx_gram_timing: the Gram launch(es) of this chunk between two events
+                if (ctx->gram_events_used == ctx->gram_events.size()) {
+                    hipEvent_t a, b;
+                    PW_TRY(hipEventCreate(&a));
+                    PW_TRY(hipEventCreate(&b));
+                    ctx->gram_events.push_back({a, b});
+                }
+                PW_TRY(hipEventRecord(ctx->gram_events[ctx->gram_events_used].first, ctx->stream));
+                ev1 = ctx->gram_events[ctx->gram_events_used].second;
+                ctx->gram_events_used++;
+            }
             rc = launch_gram_any(ctx, m, d_w, gw, n_cells, d_g, d_gt, max_sites);
             if (rc) return fail(rc);
+            if (ev1) PW_TRY(hipEventRecord(ev1, ctx->stream));
             if (params->identity_kind != IMPOP_IDENTITY_MATCH) {  // `match` sees Hamming distances only: polarity-invariant
                 rc = launch_gram_unflip(ctx, m, d_g, n_cells);
                 if (rc) return fail(rc);

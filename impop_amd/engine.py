@@ -142,6 +142,16 @@ class Context:
     def synchronize(self) -> None:
         check(self._lib.impop_ctx_synchronize(self.handle))
 
+    def gram_timing(self, enable: bool = True) -> None:
+        """HIP events around every Gram launch of pairwise_scan on this context (impop_ctx_gram_timing)."""
+        check(self._lib.impop_ctx_gram_timing(self.handle, 1 if enable else 0))
+
+    def gram_elapsed(self):
+        """-> (summed Gram-kernel ms, launches) since gram_timing(True)"""
+        t, k = C.c_double(), C.c_uint64()
+        check(self._lib.impop_ctx_gram_elapsed(self.handle, C.byref(t), C.byref(k)))
+        return t.value, k.value
+
     def close(self) -> None:
         if self._h:
             self._lib.impop_ctx_destroy(self._h)

@@ -318,6 +318,11 @@ typedef struct impop_pairwise_stats { /* 96 bytes */
 int impop_pairwise_scan(impop_ctx *ctx, const impop_matrix *m, const impop_window *windows, uint64_t n_windows,
                         const uint64_t *mask_p, const uint64_t *mask_a, const uint64_t *mask_b,
                         const impop_pairwise_params *params, impop_pairwise_stats *out_host);
+/* Measurement aid (like impop_scan_plan_timing): with timing enabled every Gram launch of impop_pairwise_scan on this context
+ * is bracketed with hipEvents on the context's stream; elapsed() synchronises and returns the summed Gram-kernel time and the
+ * number of launches since enable / reset. */
+int impop_ctx_gram_timing(impop_ctx *ctx, int enable);
+int impop_ctx_gram_elapsed(impop_ctx *ctx, double *total_ms, uint64_t *launches);
 
 /* impop_pairwise_scan over several devices, sharded like impop_scan_sharded (declared with the multi-GPU entry points
  * above; run_pica2_impg.sh:125-236 / run_h-fst.sh:155-190 with thresholds):

@@ -295,7 +295,8 @@ __device__ __forceinline__ void gram_task_fp4(const uint32_t *__restrict__ rb, u
                                               const GramWindow *__restrict__ wins, uint32_t win0, uint32_t wstep, uint32_t nchain,
                                               uint32_t ks, uint32_t ksplit, int32_t *__restrict__ out, uint64_t out_stride,
                                               uint32_t ld, uint32_t shift, bool add, const GramPlanes wp,
-                                              uint32_t ring /* LDS byte address of this wave's operand ring (wave-uniform) */) {
+                                              uint32_t ring /* LDS byte address of this wave's operand ring (wave-uniform) */,
+                                              bool out16 /* counts stored as uint16 (host: every window's W < 65536, no atomics) */) {
     constexpr int NB = DIAG ? 0 : 3;
     constexpr int NM = DIAG ? 6 : 9;  // MFMAs per phase
     constexpr int NL = DIAG ? 3 : 6;  // row groups = global loads per quad
@@ -313,7 +314,8 @@ __device__ __forceinline__ void gram_task_fp4(const uint32_t *__restrict__ rb, u
     const uint32_t win = win0 + link * wstep;
     const bool has_next = link + 1 < nchain;
     const GramWindow wn = has_next ? wins[win + wstep] : w;  // next link's bounds, long before the prefetch needs them
-    int32_t *__restrict__ o = out + (uint64_t)win * out_stride;
+    int32_t *__restrict__ o = out16 ? reinterpret_cast<int32_t *>(reinterpret_cast<uint16_t *>(out) + (uint64_t)win * out_stride)
+                                    : out + (uint64_t)win * out_stride;
     uint32_t sh = shift;
     bool stored = false;
     // Weighted sites in ONE task (wp.planes != nullptr): I = sum_k 2^k Gram(M & W_k) by Horner over the used bit planes of
@@ -342,9 +344,14 @@ __device__ __forceinline__ void gram_task_fp4(const uint32_t *__restrict__ rb, u
                 if (a < a_from || a >= a_to || (DIAG && b < a)) continue;
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
-                    int32_t *ob = o + ((uint64_t)(32 * a + (e & 3) + 8 * (e >> 2)) * ld + 32 * b);
+                    const uint64_t eo = (uint64_t)(32 * a + (e & 3) + 8 * (e >> 2)) * ld + 32 * b;  // uniform element offset of (a, b, e)
+                    int32_t *ob = o + eo;
                     // weighted matrices: this launch is bit plane `shift` of the site weights, added into the other planes' sum
                     const int32_t v = (int32_t)((uint32_t)(int32_t)acc[a][b][e] << sh);
+                    if (out16) {  // half the result bytes: a third of a short-window launch is writing 553 KB of counts per window
+                        (reinterpret_cast<uint16_t *>(o) + eo)[lane_elem] = (uint16_t)v;
+                        continue;
+                    }
 #if IMPOP_GRAM_ABLATE & 8  // timing-only build: results are not written (only one lane's worth, to keep the work alive)
                     if (lane_elem == 0xFFFFFFFFu) ob[0] = v;
                     continue;
@@ -715,7 +722,7 @@ __global__ __launch_bounds__(256, 2) void gram_fp4_kernel(const uint32_t *__rest
                                                           uint32_t tasks_per_win, uint32_t n_win, uint32_t ksplit,
                                                           const GramWindow *__restrict__ wins, int32_t *__restrict__ out,
                                                           uint32_t ld, uint64_t out_stride, uint32_t *__restrict__ queue_heads,
-                                                          uint32_t shift, bool add, GramPlanes wp, uint32_t chain) {
+                                                          uint32_t shift, bool add, GramPlanes wp, uint32_t chain, uint32_t out16) {
     extern __shared__ __attribute__((aligned(1024))) unsigned char gram_ring[];  // 4 waves x RING_BYTES (dynamic: > 64 KB)
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const uint32_t ring = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)gram_ring + wave * RING_BYTES;
@@ -744,8 +751,8 @@ __global__ __launch_bounds__(256, 2) void gram_fp4_kernel(const uint32_t *__rest
             uint32_t rem = t2 / ksplit, ti = 0;
             while (rem >= n_tiles - ti) { rem -= n_tiles - ti; ++ti; }
             const uint32_t tj = ti + rem;
-            if (ti == tj) gram_task_fp4<true>(rb, nb_row, ti, tj, wins, win, wstep, links, ks, ksplit, out, out_stride, ld, shift, add, wp, ring);
-            else gram_task_fp4<false>(rb, nb_row, ti, tj, wins, win, wstep, links, ks, ksplit, out, out_stride, ld, shift, add, wp, ring);
+            if (ti == tj) gram_task_fp4<true>(rb, nb_row, ti, tj, wins, win, wstep, links, ks, ksplit, out, out_stride, ld, shift, add, wp, ring, out16 != 0);
+            else gram_task_fp4<false>(rb, nb_row, ti, tj, wins, win, wstep, links, ks, ksplit, out, out_stride, ld, shift, add, wp, ring, out16 != 0);
         }
     }
 }
@@ -808,25 +815,30 @@ __global__ __launch_bounds__(256, 2) void gram_mfma_kernel(const uint32_t *__res
 // Exact integers.  Needed where I or a themselves matter — the `dice` identity, exported counts; the `match` identity and every
 // statistic built on it see only a_i + a_j - 2 I_ij, which is the same in both polarities, and skip this pass.
 // grid: (matrices, row chunks); dynamic LDS: n int32.
-__global__ __launch_bounds__(256) void gram_unflip_kernel(int32_t *__restrict__ g, uint32_t ld, uint64_t stride, uint32_t n, uint32_t phi) {
+template <typename T>  // int32_t, or uint16_t (counts of short windows, SimBatch.g16)
+__global__ __launch_bounds__(256) void gram_unflip_kernel(T *__restrict__ g, uint32_t ld, uint64_t stride, uint32_t n, uint32_t phi) {
     extern __shared__ int32_t unflip_t[];
-    int32_t *G = g + (uint64_t)blockIdx.x * stride;
-    for (uint32_t i = threadIdx.x; i < n; i += 256) unflip_t[i] = G[(uint64_t)i * ld + phi];
-    const int32_t P = G[(uint64_t)phi * ld + phi];
+    T *G = g + (uint64_t)blockIdx.x * stride;
+    for (uint32_t i = threadIdx.x; i < n; i += 256) unflip_t[i] = (int32_t)G[(uint64_t)i * ld + phi];
+    const int32_t P = (int32_t)G[(uint64_t)phi * ld + phi];
     __syncthreads();
     for (uint32_t i = blockIdx.y; i < n; i += gridDim.y) {
         const int32_t ri = P - unflip_t[i];
-        int32_t *row = G + (uint64_t)i * ld;
-        for (uint32_t j = i + threadIdx.x; j < n; j += 256) row[j] += ri - unflip_t[j];  // column phi itself (j = n) stays as written
+        T *row = G + (uint64_t)i * ld;
+        for (uint32_t j = i + threadIdx.x; j < n; j += 256) row[j] = (T)((int32_t)row[j] + ri - unflip_t[j]);  // column phi itself (j = n) stays as written
     }
 }
-static int launch_gram_unflip(impop_ctx *ctx, const impop_matrix *m, int32_t *d_g, uint64_t n_mats) {
+static int launch_gram_unflip(impop_ctx *ctx, const impop_matrix *m, int32_t *d_g, uint64_t n_mats, bool g16 = false) {
     if (m->phi_row == 0xFFFFFFFFu || n_mats == 0) return IMPOP_OK;
     const uint32_t n = m->g.n_hap, ld = m->n_hap_pad;
     REQUIRE(n_mats < 0x7FFFFFFFull && (size_t)n * 4 <= 64 * 1024, "gram_unflip: too many matrices / haplotypes");
     const uint32_t chunks = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(4096 / n_mats, 1), 64);
-    hipLaunchKernelGGL(gram_unflip_kernel, dim3((uint32_t)n_mats, chunks), dim3(256), (size_t)n * 4, ctx->stream, d_g, ld,
-                       (uint64_t)ld * ld, n, m->phi_row);
+    if (g16)
+        hipLaunchKernelGGL(gram_unflip_kernel<uint16_t>, dim3((uint32_t)n_mats, chunks), dim3(256), (size_t)n * 4, ctx->stream,
+                           reinterpret_cast<uint16_t *>(d_g), ld, (uint64_t)ld * ld, n, m->phi_row);
+    else
+        hipLaunchKernelGGL(gram_unflip_kernel<int32_t>, dim3((uint32_t)n_mats, chunks), dim3(256), (size_t)n * 4, ctx->stream, d_g, ld,
+                           (uint64_t)ld * ld, n, m->phi_row);
     HIP_TRY(hipGetLastError());
     return IMPOP_OK;
 }
@@ -885,8 +897,10 @@ static bool gram_use_fp4() {
 // add_shift < 0: d_out = Gram; >= 0 (FP4 kernel only): d_out += Gram << add_shift (d_out holds the other planes' sum).
 // fused_planes (FP4 kernel only): the weighted Gram matrix of m in one launch (gram_task_fp4), every window's summed
 // weight below 2^24.
+// out16 (in / out, nullable): the caller would take uint16 counts (every window's W < 65536); set to whether the launch wrote them
+// (only the FP4 kernel, only without K-split atomics and plane accumulation)
 static int launch_gram(impop_ctx *ctx, const impop_matrix *m, const uint32_t *d_rb, const GramWindow *d_wins, uint32_t n_win,
-                       int32_t *d_out, uint64_t max_window_sites, int add_shift = -1, bool fused_planes = false) {
+                       int32_t *d_out, uint64_t max_window_sites, int add_shift = -1, bool fused_planes = false, bool *out16 = nullptr) {
     const uint32_t T = m->n_hap_pad / GT;
     const uint32_t tasks_per_win = T * (T + 1) / 2;  // upper-triangular tile pairs
     // two waves per SIMD on every CU = 8 * n_cu resident waves; aim at >= 4 rounds of them so the
@@ -896,6 +910,8 @@ static int launch_gram(impop_ctx *ctx, const impop_matrix *m, const uint32_t *d_
     while ((uint64_t)n_win * tasks_per_win * ksplit < want && ksplit < 64) ksplit *= 2;
     // FP4: fp32 accumulators must stay below 2^24 per K-slice
     while (gram_use_fp4() && (max_window_sites / 128 + 2) / ksplit + 1 > FP4_MAX_SLICE_PAIRS) ksplit *= 2;
+    const bool w16 = out16 && *out16 && gram_use_fp4() && ksplit == 1 && add_shift < 0;
+    if (out16) *out16 = w16;
     if (ksplit > 1 && add_shift < 0)
         HIP_TRY(hipMemsetAsync(d_out, 0, (size_t)n_win * m->n_hap_pad * m->n_hap_pad * sizeof(int32_t), ctx->stream));
     REQUIRE((uint64_t)n_win * tasks_per_win * ksplit < 0xFFFFFFF0ull, "gram: too many tasks for one launch");
@@ -930,7 +946,7 @@ static int launch_gram(impop_ctx *ctx, const impop_matrix *m, const uint32_t *d_
     if (gram_use_fp4())
         hipLaunchKernelGGL(gram_fp4_kernel, dim3(grid), dim3(256), ring_lds, ctx->stream, d_rb, m->rb_nb, T, tasks_per_win, n_win,
                            ksplit, d_wins, d_out, m->n_hap_pad, (uint64_t)m->n_hap_pad * m->n_hap_pad, ctx->d_queue,
-                           add_shift < 0 ? 0u : (uint32_t)add_shift, add_shift >= 0, wp, chain);
+                           add_shift < 0 ? 0u : (uint32_t)add_shift, add_shift >= 0, wp, chain, w16 ? 1u : 0u);
     else
         hipLaunchKernelGGL(gram_mfma_kernel, dim3(grid), dim3(256), 0, ctx->stream, d_rb, m->rb_nb, T, tasks_per_win, n_win,
                            ksplit, d_wins, d_out, m->n_hap_pad, (uint64_t)m->n_hap_pad * m->n_hap_pad, ctx->d_queue);
@@ -1029,8 +1045,8 @@ static int ensure_weight_planes(impop_ctx *ctx, const impop_matrix *m) {
 // Gram matrices of `n_win` cells (host copy h_wins of d_wins for the cell range) into d_out; d_tmp: a second buffer
 // of the same size, used by weighted matrices only
 static int launch_gram_any(impop_ctx *ctx, const impop_matrix *m, const GramWindow *d_wins, const GramWindow *h_wins,
-                           uint32_t n_win, int32_t *d_out, int32_t *d_tmp, uint64_t max_window_sites) {
-    if (m->wt_prefix.empty()) return launch_gram(ctx, m, m->d_rb, d_wins, n_win, d_out, max_window_sites);
+                           uint32_t n_win, int32_t *d_out, int32_t *d_tmp, uint64_t max_window_sites, bool *out16 = nullptr) {
+    if (m->wt_prefix.empty()) return launch_gram(ctx, m, m->d_rb, d_wins, n_win, d_out, max_window_sites, -1, false, out16);
     int rc = ensure_weight_planes(ctx, m);
     if (rc) return rc;
     uint64_t c_lo = ~0ull, c_hi = 0;
@@ -1045,8 +1061,11 @@ static int launch_gram_any(impop_ctx *ctx, const impop_matrix *m, const GramWind
     for (uint32_t i = 0; i < n_win; ++i)
         if (h_wins[i].site_end > h_wins[i].site_begin)
             heaviest = std::max(heaviest, pre[h_wins[i].site_end] - pre[h_wins[i].site_begin]);
-    if (gram_planes_in_task() && m->wplane_bits && heaviest < GRAM_FUSED_WEIGHT_LIMIT)
-        return launch_gram(ctx, m, m->d_rb, d_wins, n_win, d_out, max_window_sites, -1, true);
+    if (gram_planes_in_task() && m->wplane_bits && heaviest < GRAM_FUSED_WEIGHT_LIMIT) {
+        if (out16 && heaviest >= 65536) *out16 = false;
+        return launch_gram(ctx, m, m->d_rb, d_wins, n_win, d_out, max_window_sites, -1, true, out16);
+    }
+    if (out16) *out16 = false;  // one launch per plane, accumulated with atomics: 32-bit counts
     REQUIRE(d_tmp || !m->wplane_bits, "weighted Gram: no buffer for the plane partials");
     HIP_TRY(hipMemsetAsync(d_out, 0, count * 4, ctx->stream));
     if (c_lo >= c_hi) return IMPOP_OK;
@@ -1504,6 +1523,9 @@ IMPOP_API int impop_pairwise_scan(impop_ctx *ctx, const impop_matrix *m, const i
     impop_window_stats *sv = reinterpret_cast<impop_window_stats *>(hmeta.data() + o_s);
     std::vector<impop_pairwise_stats> ov(cap);
     std::vector<uint32_t> add_h;
+    uint64_t call_max_W = 0;  // bounds every Gram count of the call (a cell is a window or a piece of one; compacted: + its constant)
+    for (uint64_t i = 0; i < n_windows; ++i) call_max_W = std::max(call_max_W, window_W(m, windows[i].site_begin, windows[i].site_end));
+    bool g16 = false;
     for (uint64_t base = 0; base < n_windows;) {
         // windows ord[base .. base+cnt): their cells are [c_lo, c_hi)
         uint64_t cnt = 0;
@@ -1562,16 +1584,20 @@ IMPOP_API int impop_pairwise_scan(impop_ctx *ctx, const impop_matrix *m, const i
                 ev1 = ctx->gram_events[ctx->gram_events_used].second;
                 ctx->gram_events_used++;
             }
-            rc = launch_gram_any(ctx, m, d_w, gw, n_cells, d_g, d_gt, max_sites);
+            // counts as uint16 where every count of the call fits (a count is at most its window's W): half the result bytes
+            static const bool u16_off = [] { const char *e = getenv("IMPOP_GRAM_U16"); return e && e[0] == '0'; }();
+            g16 = !u16_off && call_max_W < 65536;
+            rc = launch_gram_any(ctx, m, d_w, gw, n_cells, d_g, d_gt, max_sites, &g16);
             if (rc) return fail(rc);
             if (ev1) PW_TRY(hipEventRecord(ev1, ctx->stream));
             if (params->identity_kind != IMPOP_IDENTITY_MATCH) {  // `match` sees Hamming distances only: polarity-invariant
-                rc = launch_gram_unflip(ctx, m, d_g, n_cells);
+                rc = launch_gram_unflip(ctx, m, d_g, n_cells, g16);
                 if (rc) return fail(rc);
             }
         }
         SimBatch b{};
         b.gram = d_g; b.stride = (uint64_t)ld * ld; b.ld = ld; b.n = n; b.W = d_W; b.kind = params->identity_kind;
+        b.g16 = g16 ? 1u : 0u;
         b.round_digits = params->round_digits < 0 ? -1 : params->round_digits;
         b.seg_first = d_first; b.seg_count = d_count;
         if (compact_weighted(m)) {  // the dropped all-ones sites' summed weights, from the host prefix sums

@@ -121,7 +121,7 @@ __device__ inline JoinTest join_test(const SimView &S, const uint32_t *idx, doub
     t.by_cutoff = S.gram && S.kind == IMPOP_IDENTITY_MATCH;
     t.hstar = t.by_cutoff ? match_cutoff(S, thr) : 0;
     t.thr = thr;
-    t.vec = S.gram && !idx && (S.ld & 3u) == 0 && (S.seg_stride & 3ull) == 0 && ((uintptr_t)S.gram & 15) == 0;
+    t.vec = S.gram && !idx && gram_quads_aligned(S);
     return t;
 }
 typedef int i32q __attribute__((ext_vector_type(4)));
@@ -144,11 +144,11 @@ __device__ inline void join_blocks(const SimView &S, const JoinTest &T, const ui
             iv[u] = i32q{0, 0, 0, 0};
             if (!live[u] || o + 3 <= cs[u] || o >= m) continue;  // no position of the quad is above the seed and in range
             if (T.vec) {
-                const int32_t *g = S.gram + (uint64_t)cs[u] * S.ld + o;  // o + 3 < ld: ld is a multiple of 4 and o < m <= ld
+                const uint64_t g = (uint64_t)cs[u] * S.ld + o;  // o + 3 < ld: ld is a multiple of 4 and o < m <= ld
                 // (a window without a single Gram segment — no sites, or on a compacted matrix no VARIABLE site, among overlapping
                 // windows — has nseg == 0: its counts are the constant alone, not the first segment of the chunk)
                 i32q v = i32q{0, 0, 0, 0};
-                for (uint32_t k = 0; k < S.nseg; ++k) v += *reinterpret_cast<const i32q *>(g + k * S.seg_stride);
+                for (uint32_t k = 0; k < S.nseg; ++k) v += gram_ld4(S, g + k * S.seg_stride);
                 iv[u] = v + (int32_t)S.add;
             } else {
                 const uint32_t es = idx ? idx[cs[u]] : cs[u];
@@ -642,8 +642,7 @@ __global__ __launch_bounds__(ST, 5) void pica2_kernel(SimBatch batch, const uint
         // frequency table — f of the group a position represents, 0 for every other position, whose term then vanishes —
         // instead of one scalar Gram load per representative pair.  Every pair is present on a Gram problem, so the pair
         // count is G(G-1)/2.
-        const bool quads = S.gram && S.diag && !idx && n_el <= GG_ROWS && (S.ld & 3u) == 0 && (S.seg_stride & 3ull) == 0 &&
-                           ((uintptr_t)S.gram & 15) == 0;
+        const bool quads = S.gram && S.diag && !idx && n_el <= GG_ROWS && gram_quads_aligned(S);
         if (quads) {
             double *fpos = reinterpret_cast<double *>(rows_s);
             for (uint32_t o = tid; o < GG_ROWS; o += ST) fpos[o] = 0.0;
@@ -657,9 +656,9 @@ __global__ __launch_bounds__(ST, 5) void pica2_kernel(SimBatch batch, const uint
                 double acc = 0.0;
                 for (uint32_t o4 = 256 * (rr >> 8) + 4 * lane; o4 < n_el; o4 += 256) {
                     if (o4 + 3 <= rr) continue;  // entirely left of the diagonal
-                    const int32_t *gp = S.gram + (uint64_t)rr * S.ld + o4;  // o4 + 3 < ld: ld is a multiple of 4, o4 < n_el <= ld
+                    const uint64_t gp = (uint64_t)rr * S.ld + o4;  // o4 + 3 < ld: ld is a multiple of 4, o4 < n_el <= ld
                     i32q v = i32q{0, 0, 0, 0};  // nseg == 0: see join_blocks
-                    for (uint32_t k = 0; k < S.nseg; ++k) v += *reinterpret_cast<const i32q *>(gp + k * S.seg_stride);
+                    for (uint32_t k = 0; k < S.nseg; ++k) v += gram_ld4(S, gp + k * S.seg_stride);
                     if (S.kind == IMPOP_IDENTITY_MATCH && S.tbl && S.W < (1ull << 30)) {
                         // `match` with the memo filled (it is, from 48 groups on): the same values as the general form below, in
                         // 32-bit arithmetic with the quad's four diagonal entries as one LDS read
@@ -921,7 +920,7 @@ __global__ __launch_bounds__(ST) void hfst_kernel(SimBatch batch, const uint8_t 
         else if (cr == 1) { if (miss) ++mA; else { accA += d; ++cA; } }
         else { if (miss) ++mB; else { accB += d; ++cB; } }
     };
-    if (S.gram && cached && (S.ld & 3u) == 0) {
+    if (S.gram && cached && gram_quads_aligned(S)) {
         // Gram problems (every pair present): member rows only, lanes own FIXED columns (4 per lane and 256-column
         // step, one 16-byte load per segment), the row's class is wave-uniform and the column classes sit in a packed
         // LDS word, so a pair costs a handful of branch-free instructions: Hamming distance -> memoised identity ->
@@ -960,7 +959,7 @@ __global__ __launch_bounds__(ST) void hfst_kernel(SimBatch batch, const uint8_t 
                 const uint32_t r = k < na ? colA[k] : colB[k - na];
                 const uint32_t cr = k < na ? 1u : 2u;
                 const int64_t ar = S.diag[r];
-                const int32_t *g = S.gram + (uint64_t)r * S.ld;
+                const uint64_t g = (uint64_t)r * S.ld;
                 double toA = 0.0, toB = 0.0;
                 // the members right of r: list positions [s, cnt) of each class, 64 per step, four steps' loads in flight; the
                 // step counts are wave-uniform (scalar branches), only the last step of a class has idle lanes
@@ -979,7 +978,7 @@ __global__ __launch_bounds__(ST) void hfst_kernel(SimBatch batch, const uint8_t 
                                 const uint32_t kk = p0 + 64u * u + lane;
                                 if (kk < cnt) {
                                     c[u] = col[kk];
-                                    for (uint32_t q = 0; q < S.nseg; ++q) v[u] += g[q * S.seg_stride + c[u]];
+                                    for (uint32_t q = 0; q < S.nseg; ++q) v[u] += gram_ld1(S, g + q * S.seg_stride + c[u]);
                                 }
                             }
                         }
@@ -1023,10 +1022,10 @@ __global__ __launch_bounds__(ST) void hfst_kernel(SimBatch batch, const uint8_t 
             double same = 0.0, other = 0.0;
             for (uint32_t c4 = 4 * lane; c4 < n; c4 += 256) {
                 if (c4 + 3 <= r) continue;  // entirely left of the diagonal
-                const int32_t *g = S.gram + (uint64_t)r * S.ld + c4;
+                const uint64_t g = (uint64_t)r * S.ld + c4;
                 int64_t I[4] = {S.add, S.add, S.add, S.add};
                 for (uint32_t q = 0; q < S.nseg; ++q) {
-                    const i32v4 v = *reinterpret_cast<const i32v4 *>(g + q * S.seg_stride);
+                    const gram_i32x4 v = gram_ld4(S, g + q * S.seg_stride);
                     I[0] += v.x; I[1] += v.y; I[2] += v.z; I[3] += v.w;
                 }
                 const uint32_t cls4 = *reinterpret_cast<const uint32_t *>(cls_l + c4);  // n <= ld, LDS padded to 4

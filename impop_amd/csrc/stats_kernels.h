@@ -26,6 +26,7 @@ struct SimBatch {
     // carry, which a compacted matrix dropped (pairwise.hip)
     const uint32_t *add;
     uint32_t *err;  // optional device error word (internal.h DEV_ERR_*): set by the launch_* functions
+    uint32_t g16;   // gram mode: the counts are uint16 (pairwise.hip writes them so when every window's W < 65536: half the bytes)
 };
 
 struct SimView {
@@ -45,6 +46,7 @@ struct SimView {
     uint64_t seg_stride;  // elements between them
     int64_t add;          // constant added to every Gram entry
     uint32_t *err;        // device error word or nullptr
+    uint32_t g16;         // the Gram counts behind `gram` are uint16 (read them with gram_ld1 / gram_ld4 only)
 };
 
 constexpr uint32_t SIM_TBL_N = 1024;  // 8 KB: LDS footprint decides the occupancy of the epilogue kernels
@@ -71,12 +73,12 @@ __device__ inline SimView sim_view(const SimBatch &b, uint64_t p) {
     v.dense = b.dense ? b.dense + p * b.stride : nullptr;
     v.nseg = 1;
     v.seg_stride = b.stride;
-    if (b.gram && b.seg_first) {
-        v.gram = b.gram + (uint64_t)b.seg_first[p] * b.stride;
-        v.nseg = b.seg_count[p];
-    } else {
-        v.gram = b.gram ? b.gram + p * b.stride : nullptr;
-    }
+    const uint64_t first = (b.gram && b.seg_first) ? (uint64_t)b.seg_first[p] : p;  // index of the problem's (first) Gram matrix
+    if (b.gram && b.seg_first) v.nseg = b.seg_count[p];
+    v.g16 = b.gram ? b.g16 : 0;
+    v.gram = !b.gram ? nullptr
+             : b.g16 ? reinterpret_cast<const int32_t *>(reinterpret_cast<const uint16_t *>(b.gram) + first * b.stride)
+                     : b.gram + first * b.stride;
     v.ld = b.ld;
     v.W = b.W ? b.W[p] : 0;
     v.kind = b.kind;
@@ -89,11 +91,27 @@ __device__ inline SimView sim_view(const SimBatch &b, uint64_t p) {
     return v;
 }
 
+// element e of the problem's first Gram matrix (segment k: e + k * seg_stride), 32- or 16-bit storage
+typedef int gram_i32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned short gram_u16x4 __attribute__((ext_vector_type(4)));
+__device__ inline int32_t gram_ld1(const SimView &S, uint64_t e) {
+    return S.g16 ? (int32_t)reinterpret_cast<const uint16_t *>(S.gram)[e] : S.gram[e];
+}
+__device__ inline gram_i32x4 gram_ld4(const SimView &S, uint64_t e) {  // four consecutive elements, e a multiple of 4
+    if (S.g16) {
+        const gram_u16x4 v = *reinterpret_cast<const gram_u16x4 *>(reinterpret_cast<const uint16_t *>(S.gram) + e);
+        return gram_i32x4{(int)v.x, (int)v.y, (int)v.z, (int)v.w};
+    }
+    return *reinterpret_cast<const gram_i32x4 *>(S.gram + e);
+}
+__device__ inline bool gram_quads_aligned(const SimView &S) {  // may rows be read four elements at a time?
+    return (S.ld & 3u) == 0 && (S.seg_stride & 3ull) == 0 && ((uintptr_t)S.gram & (S.g16 ? 7 : 15)) == 0;
+}
 // Gram entry (i, j) of a problem = sum over its segments
 __device__ inline int64_t gram_at(const SimView &S, uint32_t i, uint32_t j) {
-    const int32_t *g = S.gram + (uint64_t)i * S.ld + j;
+    const uint64_t e = (uint64_t)i * S.ld + j;
     int64_t v = S.add;
-    for (uint32_t k = 0; k < S.nseg; ++k) v += g[k * S.seg_stride];
+    for (uint32_t k = 0; k < S.nseg; ++k) v += gram_ld1(S, e + k * S.seg_stride);
     return v;
 }
 

@@ -982,6 +982,16 @@ __global__ __launch_bounds__(ST) void hfst_kernel(SimBatch batch, const uint8_t 
                                 }
                             }
                         }
+                        if (S.kind == IMPOP_IDENTITY_MATCH && S.tbl && S.W < (1ull << 30)) {  // memoised `match`: 32-bit Hamming arithmetic
+                            const int32_t ar32 = (int32_t)ar, add32 = (int32_t)S.add;
+#pragma unroll
+                            for (int u = 0; u < 4; ++u)
+                                if (p0 + 64u * u < cnt && c[u] != 0xFFFFu) {
+                                    const int32_t H = ar32 + diag_l[c[u]] - 2 * (v[u] + add32);
+                                    to += 1 - ((uint32_t)H < S.tbl_n ? S.tbl[H] : match_identity(S.W, (int64_t)H, S.round_digits));
+                                }
+                            continue;
+                        }
 #pragma unroll
                         for (int u = 0; u < 4; ++u)
                             if (p0 + 64u * u < cnt && c[u] != 0xFFFFu)

@@ -749,11 +749,15 @@ for n, W in ((61, 1500), (96, 700), (200, 2100)):
     inA = (np.arange(n) % 3 == 0).astype(np.uint8); inB = (np.arange(n) % 3 == 1).astype(np.uint8)
     bm = ctx.upload_dense(m, keep_hap_major=True)
     wins = [(0, W, W), (5, W // 2, 700), (W // 3, W - 7, 0), (W // 4, W // 2 + 100, 50000)]
+    tiling = [(k * (W // 24), (k + 1) * (W // 24), 100) for k in range(24)]            # >= 8 short windows: Gram tickets are chains
+    sliding = [(k * (W // 40), k * (W // 40) + W // 10, 0) for k in range(30)]         # shared segments, chained too
     for mat in (bm, bm.compact()):
         for kind in ("match", "dice"):
             for fm in ("direct", "grouped"):
                 r = mat.pairwise_scan(wins, None, inA, inB, kind=kind, threshold=0.99, round_digits=4, fst_method=fm)
                 h.update(r.tobytes())
+            for ww in (tiling, sliding):
+                h.update(mat.pairwise_scan(ww, None, inA, inB, kind=kind, threshold=0.995, round_digits=5).tobytes())
     h.update(bm.pairwise_counts(3, W - 1).tobytes())
     h.update(bm.pairwise_identity(0, W, "dice").tobytes()); h.update(bm.pairwise_identity(10, W, "match").tobytes())
     bm.set_site_weights(rng.integers(1, 40, size=W).astype(np.uint32))
@@ -761,13 +765,16 @@ for n, W in ((61, 1500), (96, 700), (200, 2100)):
     h.update(bm.pairwise_scan(wins[:2], None, inA, inB, kind="dice", threshold=0.98, round_digits=None).tobytes())
 print(h.hexdigest())
 """
-    outs = []
-    for off in ("0", "1"):
-        env = dict(os.environ, IMPOP_NO_POLARITY=off, PYTHONPATH=ROOT)
+    # ... and the same for the other storage / scheduling choices of the all-pairs path that a caller must never see: counts as
+    # uint16 where they fit vs always int32, chains of windows per Gram ticket vs one window per ticket
+    outs = {}
+    for tag, extra in (("default", {}), ("no polarity", {"IMPOP_NO_POLARITY": "1"}), ("int32 counts", {"IMPOP_GRAM_U16": "0"}),
+                       ("no chains", {"IMPOP_GRAM_CHAIN": "1"}), ("long chains", {"IMPOP_GRAM_CHAIN": "8"})):
+        env = dict(os.environ, PYTHONPATH=ROOT, **extra)
         r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, cwd=ROOT, timeout=600)
-        assert r.returncode == 0, r.stderr[-2000:]
-        outs.append(r.stdout.strip())
-    assert outs[0] == outs[1] and len(outs[0]) == 64
+        assert r.returncode == 0, (tag, r.stderr[-2000:])
+        outs[tag] = r.stdout.strip()
+    assert len(outs["default"]) == 64 and len(set(outs.values())) == 1, outs
 
 
 def test_gram_exact_beyond_fp32_integer_range(ctx):

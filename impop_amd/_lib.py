@@ -93,6 +93,7 @@ SIGNATURES = {
     "impop_ctx_device_name": (C.c_int, [_vp, C.c_char_p, C.c_size_t]),
     "impop_matrix_upload": (C.c_int, [_vp, _u64p, C.c_uint32, C.c_uint64, C.c_uint64, C.c_uint32, C.POINTER(_vp)]),
     "impop_matrix_synthetic": (C.c_int, [_vp, C.c_uint32, C.c_uint64, C.POINTER(SynthParams), C.c_uint32, C.POINTER(_vp)]),
+    "impop_debug_raise_device_error": (C.c_int, [_vp, C.c_uint32]),
     "impop_ctx_gram_timing": (C.c_int, [_vp, C.c_int]),
     "impop_ctx_gram_elapsed": (C.c_int, [_vp, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
     "impop_matrix_synthetic_slab": (C.c_int, [_vp, C.c_uint32, C.c_uint64, C.c_uint64, C.POINTER(SynthParams), C.c_uint32, C.POINTER(_vp)]),

@@ -171,6 +171,16 @@ int ctx_err_result(impop_ctx *ctx, const char *fn) {
 }
 }  // namespace impop
 
+__global__ void raise_error_kernel(uint32_t *err, uint32_t bits) { atomicOr(err, bits); }
+
+IMPOP_API int impop_debug_raise_device_error(impop_ctx *ctx, uint32_t bits) {
+    REQUIRE(ctx && ctx->d_err, "impop_debug_raise_device_error: ctx is NULL");
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(raise_error_kernel, dim3(1), dim3(1), 0, ctx->stream, ctx->d_err, bits);
+    HIP_TRY(hipGetLastError());
+    return IMPOP_OK;
+}
+
 IMPOP_API int impop_ctx_gram_timing(impop_ctx *ctx, int enable) {
     REQUIRE(ctx, "impop_ctx_gram_timing: ctx is NULL");
     HIP_TRY(hipSetDevice(ctx->device));

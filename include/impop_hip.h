@@ -321,6 +321,10 @@ int impop_pairwise_scan(impop_ctx *ctx, const impop_matrix *m, const impop_windo
 /* Measurement aid (like impop_scan_plan_timing): with timing enabled every Gram launch of impop_pairwise_scan on this context
  * is bracketed with hipEvents on the context's stream; elapsed() synchronises and returns the summed Gram-kernel time and the
  * number of launches since enable / reset. */
+/* Test aid: ORs `bits` into the context's device error word, as a kernel whose consistency check trips would; the next call
+ * that checks the word (impop_pairwise_scan, impop_pi_from_identity, impop_fst_grouped_from_identity) returns
+ * IMPOP_E_INTERNAL and clears it. */
+int impop_debug_raise_device_error(impop_ctx *ctx, uint32_t bits);
 int impop_ctx_gram_timing(impop_ctx *ctx, int enable);
 int impop_ctx_gram_elapsed(impop_ctx *ctx, double *total_ms, uint64_t *launches);
 

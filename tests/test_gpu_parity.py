@@ -1401,6 +1401,33 @@ def test_grouping_soak_shape_regression(ctx, oracle):
             bm.free()
 
 
+def test_device_error_word_fails_the_call_and_is_cleared(ctx):
+    """A device-side consistency check that trips (the grouping's progress bound, stats.hip) ORs a bit into the context's error word;
+    the call that launched the kernel must come back as IMPOP_E_INTERNAL — never with partial results — and the word must be
+    clear again for the next call.  The bit is raised here by the ABI's test aid, the rest is the product's plumbing."""
+    import ctypes as C
+    import impop_amd
+    from impop_amd import _lib
+    lib = _lib.load()
+    sim = np.array([[1.0, 0.9995, 0.9], [0.9995, 1.0, 0.9], [0.9, 0.9, 1.0]])
+    want = ctx.pi_from_identity(sim, 0.999, None, 100)
+    _lib.check(lib.impop_debug_raise_device_error(ctx.handle, 1))
+    with pytest.raises(impop_amd.ImpopError) as e:
+        ctx.pi_from_identity(sim, 0.999, None, 100)
+    assert e.value.code == _lib.E_INTERNAL and "internal device check" in str(e.value)
+    got = ctx.pi_from_identity(sim, 0.999, None, 100)  # cleared: the same call works again
+    assert got[0] == want[0] and got[3] == want[3]
+    m = (np.random.default_rng(1).random((20, 500)) < 0.3).astype(np.uint8)
+    bm = ctx.upload_dense(m, keep_hap_major=True)
+    ok = bm.pairwise_scan([(0, 500, 500)], None, None, None, threshold=0.9, s_scope=2)
+    _lib.check(lib.impop_debug_raise_device_error(ctx.handle, 1))
+    with pytest.raises(impop_amd.ImpopError) as e:
+        bm.pairwise_scan([(0, 500, 500)], None, None, None, threshold=0.9, s_scope=2)
+    assert e.value.code == _lib.E_INTERNAL
+    assert bm.pairwise_scan([(0, 500, 500)], None, None, None, threshold=0.9, s_scope=2).tobytes() == ok.tobytes()
+    bm.free()
+
+
 def test_pica2_at_and_beyond_the_lds_limit(ctx, oracle):
     """The grouping state of a problem lives in LDS: 160 KB minus the kernel's static arrays (asked of the runtime).  A dense
     table just inside the limit runs (and agrees with the oracle); one beyond it is refused with an error, not launched."""

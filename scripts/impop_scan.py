@@ -81,9 +81,13 @@ def round_arg(v):
     return r
 
 
-def num_text(x):
-    """how a threshold is printed in the THRESHOLD column: the user's number, shortest form"""
-    return repr(float(x))
+def threshold_arg(v):
+    """-t keeps the user's TEXT next to the number: the bash drivers print "${THRESHOLD}" as typed (run_pica2_impg.sh:185-187,
+    run_fst_impg.sh:220), so `-t 0.9990` must come back as 0.9990 in the THRESHOLD column"""
+    x = float(v)
+    if not (x == x):
+        raise argparse.ArgumentTypeError("threshold must be a number")
+    return (x, v)
 
 
 class Runner:
@@ -191,7 +195,7 @@ def main():
                     "in ONE pass (replaces run_h_fst_panels.sh); one table per pair, labelled POP_A-vs-POP_B")
     ap.add_argument("-l", "--sample-list", help="tajd: sample list (run_tajd.sh -l); n = its line count")
     ap.add_argument("-u", "--subset", help="pica2: --subset-sequence-list")
-    ap.add_argument("-t", "--threshold", type=float, default=None, help="see the table above")
+    ap.add_argument("-t", "--threshold", type=threshold_arg, default=None, help="see the table above")
     ap.add_argument("-r", "--round-digits", type=round_arg, default=None, help="an integer, or `none`; see the table above")
     ap.add_argument("--fst-round-digits", type=round_arg, default=None, help="--format all: h-fst.py -r for the h-fst table")
     ap.add_argument("-p", "--region-prefix", default="CHM13#0#")
@@ -210,6 +214,9 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend when launched with WORLD_SIZE > 1 "
                     "(nccl = RCCL over xGMI; gloo for rehearsals)")
     args = ap.parse_args()
+    threshold_text = None
+    if args.threshold is not None:
+        args.threshold, threshold_text = args.threshold
     # Multi-GPU: `python -m torch.distributed.run --nproc-per-node N scripts/impop_scan.py ...` — the BED rows
     # are sharded over ranks, each rank uploads only the slab its windows touch, scans it, and ONE
     # all-gather of the fixed-size records per scan brings everything to rank 0, which prints.
@@ -382,7 +389,7 @@ def main():
         run.close()
 
     regions = [r[0] for r in rows]
-    thr_txt = num_text(pica_t)
+    thr_txt = threshold_text if threshold_text is not None else repr(float(pica_t))  # as typed, like "${THRESHOLD}" in the drivers
     r_txt = "" if pica_r is None else str(pica_r)
     if args.panel:
         p = 0

@@ -180,13 +180,14 @@ def test_batch_driver_tables(tmp_path, oracle):
             assert abs(float(t[c]) - ps) <= 1.0000001e-8, (reg, c, t[c], ps)
     # thresholded pica2 goes through the all-pairs path
     r2 = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "impop_scan.py"), "--matrix", str(tmp_path / "m.npz"),
-                         "--bed", str(tmp_path / "w.bed"), "--format", "pica2", "-t", "0.995", "-r", "4"], capture_output=True, text=True)
+                         "--bed", str(tmp_path / "w.bed"), "--format", "pica2", "-t", "0.9950", "-r", "4"], capture_output=True, text=True)
     assert r2.returncode == 0, r2.stderr
     l2 = r2.stdout.strip().split("\n")
     for k, (s0, s1, L, reg) in enumerate(wins):
         sim = oracle.identity(oracle.pairwise_counts(bits, n, s0, s1), s1 - s0, 0)
         pi, ps, _, _ = oracle.pica2(sim, 0.995, L, 4)
-        assert l2[1 + k] == f"{reg}\t{L}\t0.995\t4\t{ps:.8f} (sequence length: {L})"
+        # THRESHOLD is echoed AS TYPED, like "${THRESHOLD}" in run_pica2_impg.sh:185-187
+        assert l2[1 + k] == f"{reg}\t{L}\t0.9950\t4\t{ps:.8f} (sequence length: {L})"
 
 
 def test_batch_driver_grouped_fst(tmp_path, oracle):

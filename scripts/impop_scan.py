@@ -34,21 +34,50 @@ from impop_amd.matrixio import load_matrix
 from impop_amd.popnames import expand_population, read_subset_file
 
 
-def read_bed(path):
+def read_bed(path, fmt="tajd"):
+    """BED rows -> [(chrom, start, end)].  Comment / empty rows are skipped silently, unusable rows with the warning the
+    reference driver of that table prints on stderr: run_tajd.sh:104-117 (tajd, all), run_h-fst.sh:159-181 (hfst),
+    run_fst_impg.sh:166-179 (fst3pi), run_pica2_impg.sh:128-136 (pica2; it validates only the length)."""
     rows = []
     with open(path) as f:
-        for line in f:
+        for line_no, line in enumerate(f, 1):
             p = line.rstrip("\n").split("\t")
             if not p or not p[0] or p[0].startswith("#"):
-                continue  # run_tajd.sh:104-106
-            if len(p) < 3 or not (p[1].isdigit() and p[2].isdigit()):
-                print(f"Warning: Skipping malformed BED entry: {' '.join(p[:3])}", file=sys.stderr)  # run_tajd.sh:108-111
                 continue
-            s, e = int(p[1]), int(p[2])
-            if e - s <= 0:
-                print(f"Warning: Skipping non-positive interval length for {p[0]}:{s}-{e}", file=sys.stderr)
-                continue
-            rows.append((p[0], s, e))
+            chrom = p[0]
+            start, end = (p[1] if len(p) > 1 else ""), (p[2] if len(p) > 2 else "")
+            numeric = start.isdigit() and end.isdigit()
+            if fmt == "hfst":
+                if not start or not end:
+                    print(f"Warning: Incomplete BED entry at line {line_no}, skipping", file=sys.stderr)
+                    continue
+                if not numeric:
+                    print(f"Warning: Non-integer coordinates at line {line_no}: {chrom}:{start}-{end}, skipping", file=sys.stderr)
+                    continue
+                if int(start) >= int(end):
+                    print(f"Warning: Invalid interval at line {line_no}: {chrom}:{start}-{end}, skipping", file=sys.stderr)
+                    continue
+            elif fmt == "fst3pi":
+                if not start or not end:
+                    print(f"Warning: Incomplete BED entry for chromosome {chrom}, skipping", file=sys.stderr)
+                    continue
+                if not numeric:  # the driver's plain `echo` prints the backslash-t sequences literally
+                    print(f"Warning: Non-integer coordinates in BED entry {chrom}\\t{start}\\t{end}, skipping", file=sys.stderr)
+                    continue
+                if int(end) - int(start) <= 0:
+                    print(f"Warning: Non-positive interval length for {chrom}:{start}-{end}, skipping", file=sys.stderr)
+                    continue
+            else:
+                if not numeric:
+                    print(f"Warning: Skipping malformed BED entry: {chrom} {start} {end}", file=sys.stderr)  # run_tajd.sh:108-111
+                    continue
+                if int(end) - int(start) <= 0:
+                    if fmt == "pica2":
+                        print(f"Warning: Skipping region with non-positive length: {chrom}:{start}-{end}", file=sys.stderr)
+                    else:
+                        print(f"Warning: Skipping non-positive interval length for {chrom}:{start}-{end}", file=sys.stderr)
+                    continue
+            rows.append((chrom, int(start), int(end)))
     return rows
 
 
@@ -195,6 +224,8 @@ def main():
                     "in ONE pass (replaces run_h_fst_panels.sh); one table per pair, labelled POP_A-vs-POP_B")
     ap.add_argument("-l", "--sample-list", help="tajd: sample list (run_tajd.sh -l); n = its line count")
     ap.add_argument("-u", "--subset", help="pica2: --subset-sequence-list")
+    ap.add_argument("--sequence-length", type=int, default=None, metavar="L",
+                    help="pica2: run_pica2_impg.sh -l — the length handed to pica2 AND printed in the LENGTH column, instead of end - start")
     ap.add_argument("-t", "--threshold", type=threshold_arg, default=None, help="see the table above")
     ap.add_argument("-r", "--round-digits", type=round_arg, default=None, help="an integer, or `none`; see the table above")
     ap.add_argument("--fst-round-digits", type=round_arg, default=None, help="--format all: h-fst.py -r for the h-fst table")
@@ -281,7 +312,7 @@ def main():
     if "" in by_contig and len(mats) > 1:
         print("Error: several --matrix files need a contig name each (matrixio `contig`)", file=sys.stderr)
         sys.exit(2)
-    bed = read_bed(args.bed)
+    bed = read_bed(args.bed, fmt)
     rows, per_mat = [], {}
     for chrom, s, e in bed:
         region = f"{full_name(chrom)}:{s}-{e}"
@@ -293,6 +324,11 @@ def main():
         rows.append((region, key, s, e))
     n_rows = len(rows)
     L_col = np.array([e - s for _, _, s, e in rows], dtype=np.int64)  # LENGTH = end - start (run_pica2_impg.sh:133)
+    if args.sequence_length is not None:
+        if fmt != "pica2" or args.sequence_length <= 0:
+            print("Error: --sequence-length (a positive integer) belongs to --format pica2 (run_pica2_impg.sh -l)", file=sys.stderr)
+            sys.exit(2)
+        L_col[:] = args.sequence_length  # EFFECTIVE_LENGTH, run_pica2_impg.sh:153-157
     out = (open(args.output, "w") if args.output else sys.stdout) if rank == 0 else open(os.devnull, "w")
 
     sample_count = None
@@ -315,7 +351,7 @@ def main():
         for i in idx:
             _, _, s, e = rows[i]
             b, en = mf.site_range(s, e)
-            wins.append((b, en, e - s))
+            wins.append((b, en, int(L_col[i])))
         run = Runner(args, mf, wins, need_pairs, rank, world, local_rank)
         mask_p = mask_a = mask_b = None
         n_matched = mf.n_hap

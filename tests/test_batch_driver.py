@@ -188,6 +188,19 @@ def test_batch_driver_tables(tmp_path, oracle):
         pi, ps, _, _ = oracle.pica2(sim, 0.995, L, 4)
         # THRESHOLD is echoed AS TYPED, like "${THRESHOLD}" in run_pica2_impg.sh:185-187
         assert l2[1 + k] == f"{reg}\t{L}\t0.9950\t4\t{ps:.8f} (sequence length: {L})"
+    # run_pica2_impg.sh -l: one EFFECTIVE_LENGTH for pica2's -l and for the LENGTH column (:153-157,185-187)
+    for extra in (["-t", "0.9950", "-r", "4"], []):
+        r3 = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "impop_scan.py"), "--matrix", str(tmp_path / "m.npz"),
+                             "--bed", str(tmp_path / "w.bed"), "--format", "pica2", "--sequence-length", "777"] + extra,
+                            capture_output=True, text=True)
+        assert r3.returncode == 0, r3.stderr
+        l3 = r3.stdout.strip().split("\n")
+        for k, (s0, s1, L, reg) in enumerate(wins):
+            sim = oracle.identity(oracle.pairwise_counts(bits, n, s0, s1), s1 - s0, 0)
+            pi, ps, _, _ = oracle.pica2(sim, 0.995 if extra else 1.0, 777, 4 if extra else None)
+            t = l3[1 + k].split("\t")
+            assert t[:2] == [reg, "777"] and t[4].endswith(" (sequence length: 777)"), l3[1 + k]
+            assert abs(float(t[4].split()[0]) - ps) <= (0 if extra else 1.0000001e-8) or t[4].split()[0] == f"{ps:.8f}", (t, ps)
 
 
 def test_batch_driver_grouped_fst(tmp_path, oracle):

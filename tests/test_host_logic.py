@@ -188,3 +188,35 @@ def test_config4_sharding_geometry_of_the_c_abi():
     few = impop_amd.fixed_windows(25_000, Wn, step)
     cnts = [engine.shard_windows_c(few, 8, r)[1] for r in range(8)]
     assert sum(cnts) == len(few) and cnts == sorted(cnts, reverse=True)
+
+
+def test_batch_driver_bed_warnings_are_the_reference_drivers(tmp_path, capsys):
+    """scripts/impop_scan.py reads the BED like the driver whose table it prints: same rows kept, same stderr texts
+    (run_tajd.sh:104-117, run_h-fst.sh:159-181, run_fst_impg.sh:166-179, run_pica2_impg.sh:128-136)."""
+    import importlib.util
+    import os
+    import sys
+    from conftest import ROOT
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    spec = importlib.util.spec_from_file_location("impop_scan_cli", os.path.join(ROOT, "scripts", "impop_scan.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    bed = tmp_path / "w.bed"
+    bed.write_text("# c\n\nchr1\t10\t20\nchr1\t30\nchr1\tx\t40\nchr1\t50\t50\nchr2\t60\t70\textra\n")
+    want_rows = [("chr1", 10, 20), ("chr2", 60, 70)]
+    texts = {
+        "tajd": ["Warning: Skipping malformed BED entry: chr1 30 ", "Warning: Skipping malformed BED entry: chr1 x 40",
+                 "Warning: Skipping non-positive interval length for chr1:50-50"],
+        "hfst": ["Warning: Incomplete BED entry at line 4, skipping", "Warning: Non-integer coordinates at line 5: chr1:x-40, skipping",
+                 "Warning: Invalid interval at line 6: chr1:50-50, skipping"],
+        "fst3pi": ["Warning: Incomplete BED entry for chromosome chr1, skipping",
+                   "Warning: Non-integer coordinates in BED entry chr1\\tx\\t40, skipping",
+                   "Warning: Non-positive interval length for chr1:50-50, skipping"],
+        "pica2": ["Warning: Skipping malformed BED entry: chr1 30 ", "Warning: Skipping malformed BED entry: chr1 x 40",
+                  "Warning: Skipping region with non-positive length: chr1:50-50"],
+    }
+    for fmt, lines in texts.items():
+        assert mod.read_bed(str(bed), fmt) == want_rows
+        err = capsys.readouterr().err.strip().split("\n")
+        assert err == lines, (fmt, err)
+    assert mod.threshold_arg("0.9990") == (0.999, "0.9990") and mod.round_arg("none") == "none" and mod.round_arg("5") == 5

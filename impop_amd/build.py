@@ -14,7 +14,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 SO = os.path.join(HERE, "libimpop_hip.so")
-SOURCES = ["context.hip", "layout.hip", "scan.hip", "stats.hip", "pairwise.hip", "simparse.hip", "ehh.hip", "multigpu.hip", "gfaparse.hip"]
+SOURCES = ["context.hip", "layout.hip", "scan.hip", "stats.hip", "stats_small.hip", "pairwise.hip", "simparse.hip", "ehh.hip", "multigpu.hip", "gfaparse.hip"]
 FLAGS = [
     "-O3", "-std=c++17", "-fPIC", "-shared", "--offload-arch=gfx950",
     "-ffp-contract=off",          # fp64 epilogues follow the reference's operation order exactly

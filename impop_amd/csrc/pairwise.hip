@@ -1564,6 +1564,9 @@ IMPOP_API int impop_pairwise_scan(impop_ctx *ctx, const impop_matrix *m, const i
             swv[k] = {mw[wdx].site_begin, mw[wdx].site_end};
             owv[k] = {windows[wdx].site_begin, windows[wdx].site_end};
         }
+        // problem k IS Gram matrix k (disjoint windows, none empty): the epilogue kernels then take their one-matrix variants
+        bool one_to_one = true;
+        for (uint64_t k = 0; k < cnt && one_to_one; ++k) one_to_one = cvv[k] == 1 && fv[k] == k;
         lap("chunk metadata");
         PW_TRY(hipMemcpyAsync(d_meta, hmeta.data(), meta_bytes, hipMemcpyHostToDevice, ctx->stream));
         if (use_segmap) {
@@ -1599,7 +1602,7 @@ IMPOP_API int impop_pairwise_scan(impop_ctx *ctx, const impop_matrix *m, const i
         b.gram = d_g; b.stride = (uint64_t)ld * ld; b.ld = ld; b.n = n; b.W = d_W; b.kind = params->identity_kind;
         b.g16 = g16 ? 1u : 0u;
         b.round_digits = params->round_digits < 0 ? -1 : params->round_digits;
-        b.seg_first = d_first; b.seg_count = d_count;
+        b.seg_first = one_to_one ? nullptr : d_first; b.seg_count = one_to_one ? nullptr : d_count;
         if (compact_weighted(m)) {  // the dropped all-ones sites' summed weights, from the host prefix sums
             add_h.resize(cnt);
             for (uint64_t k = 0; k < cnt; ++k) add_h[k] = ones_weight(m, windows[ord[base + k]].site_begin, windows[ord[base + k]].site_end);

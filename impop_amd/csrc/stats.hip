@@ -13,8 +13,12 @@ namespace impop {
 constexpr uint32_t NONE = 0xFFFFFFFFu;
 constexpr int ST = 256;  // threads per problem
 
+// the wave's index in its workgroup AS A SCALAR: the compiler takes threadIdx.x >> 6 for a per-lane value, and every loop and
+// branch on it for divergent (execution masks, loads parked behind their own waits) unless it is told
+__device__ __forceinline__ uint32_t wave_index() { return (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
+
 // deterministic block sums (wave butterfly, then waves in order)
-__device__ inline double block_sum_f64(double v, double *sh /*>= ST/64*/) {
+__device__ __forceinline__ double block_sum_f64(double v, double *sh /*>= ST/64*/) {
     v = wave_sum_f64(v);
     __syncthreads();
     if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
@@ -23,7 +27,7 @@ __device__ inline double block_sum_f64(double v, double *sh /*>= ST/64*/) {
     for (int w = 0; w < ST / 64; ++w) t += sh[w];
     return t;
 }
-__device__ inline uint64_t block_sum_u64(uint64_t v, uint64_t *sh) {
+__device__ __forceinline__ uint64_t block_sum_u64(uint64_t v, uint64_t *sh) {
     v = wave_sum_u64(v);
     __syncthreads();
     if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
@@ -47,7 +51,7 @@ __device__ inline uint64_t block_sum_u64(uint64_t v, uint64_t *sh) {
 // threshold" is "H <= H*" for one H* per problem (-1: never), found by bisection with the very function the pairs
 // would be tested with — the same decisions, three integer operations per pair instead of a division and a decimal
 // rounding.  Every thread computes the same value (about 32 evaluations).
-__device__ inline int64_t match_cutoff(const SimView &S, double thr) {
+__device__ __forceinline__ int64_t match_cutoff(const SimView &S, double thr) {
     const int64_t W = (int64_t)S.W;
     auto above = [&](int64_t H) { const double v = match_identity(S.W, H, S.round_digits); return v == v && v > thr; };
     if (!above(0)) return -1;
@@ -88,20 +92,20 @@ struct Pica2Split {
     double *rowsum;    // problem p: n_el doubles
     uint64_t *adj;     // nullable; problem p: n_el rows of 4 ceil(n_el / 256) words (layout above): "o > i and o joins seed i"
 };
-__device__ inline uint32_t *split_tab(const Pica2Split &sp, uint64_t p, uint32_t n_el) { return sp.tab + p * (2ull * n_el + 4); }
+__device__ __forceinline__ uint32_t *split_tab(const Pica2Split &sp, uint64_t p, uint32_t n_el) { return sp.tab + p * (2ull * n_el + 4); }
 
-__host__ __device__ inline uint32_t bit_words(uint32_t m) { return 4 * ((m + 255) / 256); }
-__device__ inline uint32_t bit_word(uint32_t o) { return 4 * (o >> 8) + (o & 3); }
-__device__ inline uint32_t bit_lane(uint32_t o) { return (o & 255) >> 2; }
-__device__ inline uint32_t bit_pos(uint32_t w, uint32_t L) { return 256 * (w >> 2) + 4 * L + (w & 3); }
-__device__ inline uint64_t readlane_u64(uint64_t v, uint32_t l /*uniform*/) {
+__host__ __device__ __forceinline__ uint32_t bit_words(uint32_t m) { return 4 * ((m + 255) / 256); }
+__device__ __forceinline__ uint32_t bit_word(uint32_t o) { return 4 * (o >> 8) + (o & 3); }
+__device__ __forceinline__ uint32_t bit_lane(uint32_t o) { return (o & 255) >> 2; }
+__device__ __forceinline__ uint32_t bit_pos(uint32_t w, uint32_t L) { return 256 * (w >> 2) + 4 * L + (w & 3); }
+__device__ __forceinline__ uint64_t readlane_u64(uint64_t v, uint32_t l /*uniform*/) {
     const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, (int)l);
     const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), (int)l);
     return ((uint64_t)hi << 32) | lo;
 }
 // word w (< 128, PER LANE) of a 128-word set whose words l and l + 64 live in lane l's u0 / u1: a register exchange
 // (ds_bpermute_b32: lane i receives the source register of lane addr_i / 4).  Every lane of the wave must execute it.
-__device__ inline uint64_t lane_word(uint64_t u0, uint64_t u1, uint32_t w) {
+__device__ __forceinline__ uint64_t lane_word(uint64_t u0, uint64_t u1, uint32_t w) {
     const int a = (int)((w & 63) << 2);
     const uint32_t lo0 = (uint32_t)__builtin_amdgcn_ds_bpermute(a, (int)(uint32_t)u0);
     const uint32_t hi0 = (uint32_t)__builtin_amdgcn_ds_bpermute(a, (int)(uint32_t)(u0 >> 32));
@@ -116,7 +120,7 @@ struct JoinTest {  // "identity(seed, o) > threshold", as greedy_groups tests it
     int64_t hstar;
     double thr;
 };
-__device__ inline JoinTest join_test(const SimView &S, const uint32_t *idx, double thr) {
+__device__ __forceinline__ JoinTest join_test(const SimView &S, const uint32_t *idx, double thr) {
     JoinTest t;
     t.by_cutoff = S.gram && S.kind == IMPOP_IDENTITY_MATCH;
     t.hstar = t.by_cutoff ? match_cutoff(S, thr) : 0;
@@ -126,14 +130,14 @@ __device__ inline JoinTest join_test(const SimView &S, const uint32_t *idx, doub
 }
 typedef int i32q __attribute__((ext_vector_type(4)));
 // word `k` (0..3, varying by lane) of four uniform words, without indexing a register array by a lane value
-__device__ inline uint64_t pick4(const uint64_t (&w)[4], uint32_t k) { return k == 0 ? w[0] : k == 1 ? w[1] : k == 2 ? w[2] : w[3]; }
+__device__ __forceinline__ uint64_t pick4(const uint64_t (&w)[4], uint32_t k) { return k == 0 ? w[0] : k == 1 ? w[1] : k == 2 ? w[2] : w[3]; }
 
 // the four words of 256-block hs[k] of candidate cs[k]'s row, for U items (live[k] false = nothing to do): all loads of
 // the U items go out before the first is consumed.  Registers decide how many problems a CU holds at once, so only what
 // must wait for memory is kept per item: the shared counts I (the two diagonal entries come from LDS when the bit is
 // formed) or the identities.
 template <int U>
-__device__ inline void join_blocks(const SimView &S, const JoinTest &T, const uint32_t *__restrict__ idx, uint32_t m,
+__device__ __forceinline__ void join_blocks(const SimView &S, const JoinTest &T, const uint32_t *__restrict__ idx, uint32_t m,
                                    const uint32_t (&cs)[U], const uint32_t (&hs)[U], const bool (&live)[U], uint64_t (&bits)[U][4]) {
     const uint32_t lane = threadIdx.x & 63;
     if (S.gram) {
@@ -249,7 +253,7 @@ __global__ __launch_bounds__(ST) void pica2_adj_kernel(SimBatch batch, const uin
     const uint32_t aw = bit_words(n_el), nh = aw / 4;
     uint64_t *adj = split.adj + prob * (uint64_t)n_el * aw;
     constexpr int AU = 4;
-    for (uint32_t i = (tid >> 6) + (ST / 64) * blockIdx.y; i < n_el; i += (ST / 64) * gridDim.y) {
+    for (uint32_t i = wave_index() + (ST / 64) * blockIdx.y; i < n_el; i += (ST / 64) * gridDim.y) {
         for (uint32_t h0 = i >> 8; h0 < nh; h0 += AU) {
             uint32_t cs[AU], hs[AU];
             bool live[AU];
@@ -266,7 +270,7 @@ __global__ __launch_bounds__(ST) void pica2_adj_kernel(SimBatch batch, const uin
 
 constexpr uint32_t GG_ROWS = 512;  // words of candidate rows a small problem's block may take (the kernels declare them)
 template <bool FROM_ADJ>
-__device__ inline uint32_t greedy_groups_bits(const uint64_t *__restrict__ adj, const SimView &S, const uint32_t *__restrict__ idx,
+__device__ __forceinline__ uint32_t greedy_groups_bits(const uint64_t *__restrict__ adj, const SimView &S, const uint32_t *__restrict__ idx,
                                               double thr, uint32_t m, uint32_t *grp, uint32_t *gsz, uint32_t *rep, uint64_t *rows_big,
                                               uint64_t *rows_small /*LDS, GG_ROWS words (unused with FROM_ADJ)*/) {
     constexpr int JU = 4;               // (candidate, 256-block) items in flight per wave
@@ -341,7 +345,7 @@ __device__ inline uint32_t greedy_groups_bits(const uint64_t *__restrict__ adj, 
         if (n == 0) { done = true; break; }
         if (FROM_ADJ) {
             constexpr int RU = 8;  // candidate rows in flight per wave
-            for (uint32_t b0 = tid >> 6; b0 < n; b0 += (ST / 64) * RU) {
+            for (uint32_t b0 = wave_index(); b0 < n; b0 += (ST / 64) * RU) {
                 uint64_t v[RU][2];
 #pragma unroll
                 for (int u = 0; u < RU; ++u) {
@@ -365,7 +369,7 @@ __device__ inline uint32_t greedy_groups_bits(const uint64_t *__restrict__ adj, 
             }
         } else {
             const uint32_t items = n * nh;  // item = (candidate b, block h): rows[b * aw + 4 h .. + 4]
-            for (uint32_t it0 = (tid >> 6) * JU; it0 < items; it0 += (ST / 64) * JU) {
+            for (uint32_t it0 = wave_index() * JU; it0 < items; it0 += (ST / 64) * JU) {
                 uint32_t cs[JU], hs[JU];
                 bool live[JU];
                 uint64_t bits[JU][4];
@@ -467,7 +471,7 @@ __device__ inline uint32_t greedy_groups_bits(const uint64_t *__restrict__ adj, 
     return G;
 }
 
-__device__ inline uint32_t greedy_groups(const SimView &S, const uint32_t *__restrict__ idx, uint32_t m, double thr,
+__device__ __forceinline__ uint32_t greedy_groups(const SimView &S, const uint32_t *__restrict__ idx, uint32_t m, double thr,
                                          const uint32_t *__restrict__ order, uint32_t *grp, uint32_t *gsz, uint32_t *rep,
                                          uint32_t *scratch, uint64_t *rows_s /*LDS, GG_ROWS words*/) {
     // seeds in position order: the blocked form above (same groups, no barrier and round trip per group); the loop below
@@ -558,6 +562,16 @@ __device__ inline uint32_t greedy_groups(const SimView &S, const uint32_t *__res
 // row sums); pica2_rows_kernel (grid: problems x row chunks) fills the row sums; pica2_finish_kernel adds them in row
 // order and writes the record.  Small problems do everything in pica2_kernel, as before.
 
+// FAST: what the launch knows about a batch of Gram problems, as compile-time constants — 0 nothing (any batch), 1 uint16 counts
+// and exactly one Gram matrix per problem, 2 int32 counts and one matrix.  With them the "16 or 32 bit" branch and the segment
+// loop around every Gram load fold away, and the loads of a batch of items really are in flight together (as runtime values each
+// load sat in its own basic block behind a wait: three quarters of the waves' cycles were spent parked on memory,
+// profiles/r03_epilogue_pmc.txt).
+template <int FAST>
+__device__ __forceinline__ void sim_view_fast(SimView &S) {
+    if (FAST) { S.dense = nullptr; S.nseg = 1; S.g16 = FAST == 1 ? 1u : 0u; }
+}
+template <int FAST>
 __global__ __launch_bounds__(ST, 5) void pica2_kernel(SimBatch batch, const uint32_t *__restrict__ idx, uint32_t n_el,
                                                    const uint32_t *__restrict__ order, double threshold,
                                                    const uint64_t *__restrict__ seq_len, Pica2Out *__restrict__ out,
@@ -571,6 +585,7 @@ __global__ __launch_bounds__(ST, 5) void pica2_kernel(SimBatch batch, const uint
     __shared__ uint64_t sh_npairs;
     const uint64_t prob = blockIdx.x;
     SimView S = sim_view(batch, prob);  // no identity memo here: with few groups it costs more than it saves
+    sim_view_fast<FAST>(S);
     const uint32_t tid = threadIdx.x;
     if (tid == 0) { sh_have = 0; sh_npairs = 0; }
     if (S.gram) {  // Gram problems: the diagonal a_i in LDS (behind the other arrays), else every identity costs three loads
@@ -649,7 +664,7 @@ __global__ __launch_bounds__(ST, 5) void pica2_kernel(SimBatch batch, const uint
             __syncthreads();
             for (uint32_t g = tid; g < G; g += ST) fpos[rep[g]] = (double)gsz[g] / total;
             __syncthreads();
-            for (uint32_t i = tid >> 6; i < G; i += ST / 64) {
+            for (uint32_t i = wave_index(); i < G; i += ST / 64) {
                 const uint32_t rr = rep[i];
                 const double fi = (double)gsz[i] / total;
                 const int64_t ar = S.diag[rr];
@@ -703,7 +718,7 @@ __global__ __launch_bounds__(ST, 5) void pica2_kernel(SimBatch batch, const uint
             for (uint32_t g = tid; g < G; g += ST) ftab[g] = (double)gsz[g] / total;
             __syncthreads();
         }
-        for (uint32_t i = tid >> 6; i < G; i += ST / 64) {
+        for (uint32_t i = wave_index(); i < G; i += ST / 64) {
             const uint32_t ri = idx ? idx[rep[i]] : rep[i];
             const double fi = (double)gsz[i] / total;
             double acc = 0.0;
@@ -777,7 +792,7 @@ __global__ __launch_bounds__(ST) void pica2_rows_kernel(SimBatch batch, const ui
     uint32_t have = 0;
     uint64_t npairs = 0;
     constexpr int P2_U = 8;
-    for (uint32_t i = (tid >> 6) + (ST / 64) * blockIdx.y; i < G; i += (ST / 64) * gridDim.y) {
+    for (uint32_t i = wave_index() + (ST / 64) * blockIdx.y; i < G; i += (ST / 64) * gridDim.y) {
         const uint32_t ri = idx ? idx[rep[i]] : rep[i];
         const double fi = (double)gsz[i] / total;
         double acc = 0.0;
@@ -855,24 +870,6 @@ struct HfstPart {
     double a, b, x;
     uint64_t ca, cb, cx;
 };
-__device__ inline void hfst_outputs(double accA, double accB, double accX, uint64_t cA, uint64_t mA, uint64_t cB, uint64_t mB,
-                                    uint64_t cX, uint64_t mX, uint64_t L, HfstOut *__restrict__ dst) {
-    const double pi_a = cA ? accA / (double)cA : 0.0;  // h-fst.py:168-171
-    const double pi_b = cB ? accB / (double)cB : 0.0;
-    const double dxy = cX ? accX / (double)cX : 0.0;
-    const double pi_xy = 0.5 * (pi_a + pi_b);                   // :203
-    const double fst = (dxy > 0) ? (dxy - pi_xy) / dxy : 0.0;   // :214-221
-    HfstOut o;
-    if (L > 0) {  // :225-240
-        const double dl = (double)L;
-        o.v[0] = fst; o.v[1] = pi_a / dl; o.v[2] = pi_b / dl; o.v[3] = pi_xy / dl; o.v[4] = dxy / dl;
-        o.v[5] = (dxy - pi_xy) / dl;
-    } else {
-        o.v[0] = fst; o.v[1] = pi_a; o.v[2] = pi_b; o.v[3] = pi_xy; o.v[4] = dxy; o.v[5] = dxy - pi_xy;
-    }
-    o.cnt[0] = cA; o.cnt[1] = mA; o.cnt[2] = cB; o.cnt[3] = mB; o.cnt[4] = cX; o.cnt[5] = mX;
-    *dst = o;
-}
 __global__ void hfst_finish_kernel(const HfstPart *__restrict__ part, uint32_t splits, uint64_t n_problems,
                                    const uint64_t *__restrict__ seq_len, HfstOut *__restrict__ out) {
     const uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -883,6 +880,7 @@ __global__ void hfst_finish_kernel(const HfstPart *__restrict__ part, uint32_t s
     hfst_outputs(a, b, x, q.ca, 0, q.cb, 0, q.cx, 0, seq_len ? seq_len[p] : 0, out + p);
 }
 
+template <int FAST>
 __global__ __launch_bounds__(ST) void hfst_kernel(SimBatch batch, const uint8_t *__restrict__ in_a,
                                                   const uint8_t *__restrict__ in_b, const uint64_t *__restrict__ seq_len,
                                                   HfstOut *__restrict__ out, HfstPart *__restrict__ part) {
@@ -892,6 +890,7 @@ __global__ __launch_bounds__(ST) void hfst_kernel(SimBatch batch, const uint8_t 
     __shared__ double sim_tbl[SIM_TBL_N];
     const uint64_t prob = blockIdx.x;
     SimView S = sim_view(batch, prob);
+    sim_view_fast<FAST>(S);
     sim_table_fill(S, sim_tbl, ST);
     const uint32_t n = batch.n, tid = threadIdx.x;
     const bool cached = n <= HF_LDS_N;
@@ -955,7 +954,7 @@ __global__ __launch_bounds__(ST) void hfst_kernel(SimBatch batch, const uint8_t 
             }
             __syncthreads();
             const uint32_t na = n_a, nb = n_b, nmem = n_members;
-            for (uint32_t k = tid >> 6; k < nmem; k += ST / 64) {
+            for (uint32_t k = wave_index(); k < nmem; k += ST / 64) {
                 const uint32_t r = k < na ? colA[k] : colB[k - na];
                 const uint32_t cr = k < na ? 1u : 2u;
                 const int64_t ar = S.diag[r];
@@ -1025,7 +1024,7 @@ __global__ __launch_bounds__(ST) void hfst_kernel(SimBatch batch, const uint8_t 
         }
         __syncthreads();
         const uint32_t nm = n_members;
-        for (uint32_t k = (tid >> 6) + (ST / 64) * blockIdx.y; k < nm; k += (ST / 64) * gridDim.y) {
+        for (uint32_t k = wave_index() + (ST / 64) * blockIdx.y; k < nm; k += (ST / 64) * gridDim.y) {
             const uint32_t r = rows_l[k];
             const uint32_t cr = cls_l[r];
             const int64_t ar = S.diag[r];
@@ -1062,7 +1061,7 @@ __global__ __launch_bounds__(ST) void hfst_kernel(SimBatch batch, const uint8_t 
         }
         }
     } else
-    for (uint32_t r = tid >> 6; r < n; r += ST / 64) {
+    for (uint32_t r = wave_index(); r < n; r += ST / 64) {
         const uint32_t cr = cached ? cls_l[r] : cls_of(r);  // wave-uniform
         if (!cr) continue;
         for (uint32_t c = r + 1 + lane; c < n; c += 64) {
@@ -1091,7 +1090,7 @@ __global__ __launch_bounds__(ST) void hfst_kernel(SimBatch batch, const uint8_t 
 // population, frequency-weighted sums over group pairs with the first pair present in the table
 // (members in sorted order) as the groups' similarity.
 // hud.py:88-99 get_group_similarity: first (member of g1) x (member of g2) pair that is present
-__device__ inline double hud_first_found(const SimView &S, const uint32_t *ia, const uint32_t *ga, uint32_t ma, uint32_t g1,
+__device__ __forceinline__ double hud_first_found(const SimView &S, const uint32_t *ia, const uint32_t *ga, uint32_t ma, uint32_t g1,
                                          const uint32_t *ib, const uint32_t *gb, uint32_t mb, uint32_t g2) {
     for (uint32_t i = 0; i < ma; ++i) {
         if (ga[i] != g1) continue;
@@ -1281,14 +1280,24 @@ static size_t dynamic_lds_room(const void *kernel) {
     return used < total ? total - used : 0;
 }
 
+// which kernel variant a batch may take (pica2_kernel / hfst_kernel FAST): Gram problems, one matrix per problem at index p
+static int sim_batch_fast(const SimBatch &b) {
+    static const bool off = [] { const char *e = getenv("IMPOP_EPILOGUE_FAST"); return e && e[0] == '0'; }();  // A/B and test switch
+    if (off || !b.gram || b.dense || b.seg_first || b.seg_count) return 0;
+    return b.g16 ? 1 : 2;
+}
+
 int launch_pica2(impop_ctx *ctx, const SimBatch &b, uint64_t n_problems, const uint32_t *d_idx, uint32_t n_el,
                  const uint32_t *d_order, double threshold, const uint64_t *d_seq_len, Pica2Out *d_out,
                  uint32_t *d_group_of) {
     if (!n_problems) return IMPOP_OK;
+    REQUIRE(n_problems < 0x7FFFFFFFull, "pica2: too many problems");
+    if (pica2_small_applies(b, n_el, d_order, d_group_of))  // the window-statistics shape: stats_small.hip
+        return launch_pica2_small(ctx, b, n_problems, d_idx, n_el, threshold, d_seq_len, d_out);
     const size_t lds = (size_t)n_el * (8 + 12) + (b.gram ? (size_t)b.n * 4 : 0) + 16;
     // 160 KB per workgroup, minus the kernel's static arrays (identity memo, candidate rows of the grouping, counters:
     // ~14 KB) — asked of the runtime, so that the limit follows the kernel
-    static const size_t lds_room = dynamic_lds_room((const void *)pica2_kernel);
+    static const size_t lds_room = dynamic_lds_room((const void *)pica2_kernel<0>);  // the variants share their static arrays
     REQUIRE(lds <= lds_room, "pica2: %u elements exceed the LDS-resident grouping limit (about 7300; 6100 on Gram problems)", n_el);
     REQUIRE(n_problems < 0x7FFFFFFFull, "pica2: too many problems");
     // few large problems: Step 2 is split over row chunks (about 8 workgroups per CU in total, >= 16 rows each)
@@ -1317,12 +1326,20 @@ int launch_pica2(impop_ctx *ctx, const SimBatch &b, uint64_t n_problems, const u
             HIP_TRY(hipGetLastError());
         }
     }
-    if (lds > 48 * 1024)
-        HIP_TRY(hipFuncSetAttribute((const void *)pica2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     SimBatch be = b;
     be.err = ctx->d_err;  // the grouping's progress bound reports here (ctx_err_fetch / ctx_err_result in the caller)
-    hipLaunchKernelGGL(pica2_kernel, dim3((uint32_t)n_problems), dim3(ST), lds, ctx->stream, be, d_idx, n_el, d_order,
-                       threshold, d_seq_len, d_out, d_group_of, split);
+    const int fast = sim_batch_fast(b);
+    const void *kfn = fast == 1 ? (const void *)pica2_kernel<1> : fast == 2 ? (const void *)pica2_kernel<2> : (const void *)pica2_kernel<0>;
+    if (lds > 48 * 1024) HIP_TRY(hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    if (fast == 1)
+        hipLaunchKernelGGL(pica2_kernel<1>, dim3((uint32_t)n_problems), dim3(ST), lds, ctx->stream, be, d_idx, n_el, d_order, threshold,
+                           d_seq_len, d_out, d_group_of, split);
+    else if (fast == 2)
+        hipLaunchKernelGGL(pica2_kernel<2>, dim3((uint32_t)n_problems), dim3(ST), lds, ctx->stream, be, d_idx, n_el, d_order, threshold,
+                           d_seq_len, d_out, d_group_of, split);
+    else
+        hipLaunchKernelGGL(pica2_kernel<0>, dim3((uint32_t)n_problems), dim3(ST), lds, ctx->stream, be, d_idx, n_el, d_order, threshold,
+                           d_seq_len, d_out, d_group_of, split);
     HIP_TRY(hipGetLastError());
     if (chunks > 1) {
         hipLaunchKernelGGL(pica2_rows_kernel, dim3((uint32_t)n_problems, chunks), dim3(ST), b.gram ? (size_t)b.n * 4 : 0, ctx->stream, b,
@@ -1339,6 +1356,7 @@ int launch_hfst(impop_ctx *ctx, const SimBatch &b, uint64_t n_problems, const ui
                 const uint64_t *d_seq_len, HfstOut *d_out) {
     if (!n_problems) return IMPOP_OK;
     REQUIRE(n_problems < 0x7FFFFFFFull, "hfst: too many problems");
+    if (hfst_small_applies(b)) return launch_hfst_small(ctx, b, n_problems, d_in_a, d_in_b, d_seq_len, d_out);  // stats_small.hip
     // diag[n4] int32 | cls[n4] u8 | (16-aligned) member rows[n] u32, n4 = n rounded up to 4
     const size_t n4 = ((size_t)b.n + 3) & ~(size_t)3;
     const size_t lds = b.n <= HF_LDS_N ? ((n4 * 5 + 15) & ~(size_t)15) + (size_t)b.n * 4 + 16 : 16;
@@ -1357,8 +1375,16 @@ int launch_hfst(impop_ctx *ctx, const SimBatch &b, uint64_t n_problems, const ui
         if (arc) return arc;
         d_part = reinterpret_cast<HfstPart *>(aux);
     }
-    hipLaunchKernelGGL(hfst_kernel, dim3((uint32_t)n_problems, splits), dim3(ST), lds, ctx->stream, b, d_in_a, d_in_b, d_seq_len,
-                       d_out, d_part);
+    const int fast = sim_batch_fast(b);
+    if (fast == 1)
+        hipLaunchKernelGGL(hfst_kernel<1>, dim3((uint32_t)n_problems, splits), dim3(ST), lds, ctx->stream, b, d_in_a, d_in_b, d_seq_len,
+                           d_out, d_part);
+    else if (fast == 2)
+        hipLaunchKernelGGL(hfst_kernel<2>, dim3((uint32_t)n_problems, splits), dim3(ST), lds, ctx->stream, b, d_in_a, d_in_b, d_seq_len,
+                           d_out, d_part);
+    else
+        hipLaunchKernelGGL(hfst_kernel<0>, dim3((uint32_t)n_problems, splits), dim3(ST), lds, ctx->stream, b, d_in_a, d_in_b, d_seq_len,
+                           d_out, d_part);
     HIP_TRY(hipGetLastError());
     if (splits > 1) {
         hipLaunchKernelGGL(hfst_finish_kernel, dim3((uint32_t)((n_problems + 63) / 64)), dim3(64), 0, ctx->stream, d_part, splits,

@@ -51,14 +51,14 @@ struct SimView {
 
 constexpr uint32_t SIM_TBL_N = 1024;  // 8 KB: LDS footprint decides the occupancy of the epilogue kernels
 
-__device__ inline double match_identity(uint64_t W, int64_t H, int round_digits) {
+__device__ __forceinline__ double match_identity(uint64_t W, int64_t H, int round_digits) {
     double v = W ? (double)((int64_t)W - H) / (double)W : 1.0;
     if (round_digits >= 0) v = py_round(v, round_digits);
     return v;
 }
 
 // cooperative fill by the whole workgroup (call before any sim_get; caller synchronises)
-__device__ inline void sim_table_fill(SimView &S, double *lds_tbl, uint32_t n_threads) {
+__device__ __forceinline__ void sim_table_fill(SimView &S, double *lds_tbl, uint32_t n_threads) {
     S.tbl = nullptr;
     S.tbl_n = 0;
     if (S.gram && S.kind == IMPOP_IDENTITY_MATCH) {
@@ -68,7 +68,7 @@ __device__ inline void sim_table_fill(SimView &S, double *lds_tbl, uint32_t n_th
     }
 }
 
-__device__ inline SimView sim_view(const SimBatch &b, uint64_t p) {
+__device__ __forceinline__ SimView sim_view(const SimBatch &b, uint64_t p) {
     SimView v;
     v.dense = b.dense ? b.dense + p * b.stride : nullptr;
     v.nseg = 1;
@@ -94,21 +94,21 @@ __device__ inline SimView sim_view(const SimBatch &b, uint64_t p) {
 // element e of the problem's first Gram matrix (segment k: e + k * seg_stride), 32- or 16-bit storage
 typedef int gram_i32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned short gram_u16x4 __attribute__((ext_vector_type(4)));
-__device__ inline int32_t gram_ld1(const SimView &S, uint64_t e) {
+__device__ __forceinline__ int32_t gram_ld1(const SimView &S, uint64_t e) {
     return S.g16 ? (int32_t)reinterpret_cast<const uint16_t *>(S.gram)[e] : S.gram[e];
 }
-__device__ inline gram_i32x4 gram_ld4(const SimView &S, uint64_t e) {  // four consecutive elements, e a multiple of 4
+__device__ __forceinline__ gram_i32x4 gram_ld4(const SimView &S, uint64_t e) {  // four consecutive elements, e a multiple of 4
     if (S.g16) {
         const gram_u16x4 v = *reinterpret_cast<const gram_u16x4 *>(reinterpret_cast<const uint16_t *>(S.gram) + e);
         return gram_i32x4{(int)v.x, (int)v.y, (int)v.z, (int)v.w};
     }
     return *reinterpret_cast<const gram_i32x4 *>(S.gram + e);
 }
-__device__ inline bool gram_quads_aligned(const SimView &S) {  // may rows be read four elements at a time?
+__device__ __forceinline__ bool gram_quads_aligned(const SimView &S) {  // may rows be read four elements at a time?
     return (S.ld & 3u) == 0 && (S.seg_stride & 3ull) == 0 && ((uintptr_t)S.gram & (S.g16 ? 7 : 15)) == 0;
 }
 // Gram entry (i, j) of a problem = sum over its segments
-__device__ inline int64_t gram_at(const SimView &S, uint32_t i, uint32_t j) {
+__device__ __forceinline__ int64_t gram_at(const SimView &S, uint32_t i, uint32_t j) {
     const uint64_t e = (uint64_t)i * S.ld + j;
     int64_t v = S.add;
     for (uint32_t k = 0; k < S.nseg; ++k) v += gram_ld1(S, e + k * S.seg_stride);
@@ -116,7 +116,7 @@ __device__ inline int64_t gram_at(const SimView &S, uint32_t i, uint32_t j) {
 }
 
 // identity from the Gram counts of a pair: I = shared sites, ai / aj = sites carried by i / by j
-__device__ inline double sim_from_gram(const SimView &S, int64_t I, int64_t ai, int64_t aj) {
+__device__ __forceinline__ double sim_from_gram(const SimView &S, int64_t I, int64_t ai, int64_t aj) {
     double v;
     if (S.kind == IMPOP_IDENTITY_MATCH) {
         const int64_t H = ai + aj - 2 * I;
@@ -131,7 +131,7 @@ __device__ inline double sim_from_gram(const SimView &S, int64_t I, int64_t ai, 
 }
 
 // identity of the unordered pair {i, j}; NaN = pair absent (pica2.py:85-87 keying)
-__device__ inline double sim_get(const SimView &S, uint32_t i, uint32_t j) {
+__device__ __forceinline__ double sim_get(const SimView &S, uint32_t i, uint32_t j) {
     if (i > j) { const uint32_t t = i; i = j; j = t; }
     if (!S.dense)
         return sim_from_gram(S, gram_at(S, i, j), S.diag ? S.diag[i] : gram_at(S, i, i), S.diag ? S.diag[j] : gram_at(S, j, j));
@@ -151,6 +151,34 @@ struct HfstOut {
     double v[6];       // fst, pi_a, pi_b, pi_xy, dxy, da
     uint64_t cnt[6];   // pairs_a, miss_a, pairs_b, miss_b, pairs_between, miss_between
 };
+
+// h-fst.py:168-240: the six outputs from the three sums and the pair / missing-pair counts
+__device__ __forceinline__ void hfst_outputs(double accA, double accB, double accX, uint64_t cA, uint64_t mA, uint64_t cB, uint64_t mB,
+                                    uint64_t cX, uint64_t mX, uint64_t L, HfstOut *__restrict__ dst) {
+    const double pi_a = cA ? accA / (double)cA : 0.0;  // h-fst.py:168-171
+    const double pi_b = cB ? accB / (double)cB : 0.0;
+    const double dxy = cX ? accX / (double)cX : 0.0;
+    const double pi_xy = 0.5 * (pi_a + pi_b);                   // :203
+    const double fst = (dxy > 0) ? (dxy - pi_xy) / dxy : 0.0;   // :214-221
+    HfstOut o;
+    if (L > 0) {  // :225-240
+        const double dl = (double)L;
+        o.v[0] = fst; o.v[1] = pi_a / dl; o.v[2] = pi_b / dl; o.v[3] = pi_xy / dl; o.v[4] = dxy / dl;
+        o.v[5] = (dxy - pi_xy) / dl;
+    } else {
+        o.v[0] = fst; o.v[1] = pi_a; o.v[2] = pi_b; o.v[3] = pi_xy; o.v[4] = dxy; o.v[5] = dxy - pi_xy;
+    }
+    o.cnt[0] = cA; o.cnt[1] = mA; o.cnt[2] = cB; o.cnt[3] = mB; o.cnt[4] = cX; o.cnt[5] = mX;
+    *dst = o;
+}
+
+// the window-statistics shape (Gram problems of <= 512 sequences, `match`, uint16 counts, one matrix per problem): stats_small.hip
+bool pica2_small_applies(const SimBatch &b, uint32_t n_el, const uint32_t *d_order, const uint32_t *d_group_of);
+bool hfst_small_applies(const SimBatch &b);
+int launch_pica2_small(impop_ctx *ctx, const SimBatch &b, uint64_t n_problems, const uint32_t *d_idx, uint32_t n_el, double threshold,
+                       const uint64_t *d_seq_len, Pica2Out *d_out);
+int launch_hfst_small(impop_ctx *ctx, const SimBatch &b, uint64_t n_problems, const uint8_t *d_in_a, const uint8_t *d_in_b,
+                      const uint64_t *d_seq_len, HfstOut *d_out);
 
 // d_order (nullable): seed order of the greedy grouping as positions into the element list (stats.hip greedy_groups)
 int launch_pica2(impop_ctx *ctx, const SimBatch &b, uint64_t n_problems, const uint32_t *d_idx, uint32_t n_el,

@@ -741,6 +741,7 @@ import numpy as np
 import impop_amd
 ctx = impop_amd.Context(0)
 h = hashlib.sha256()
+recs = []
 rng = np.random.default_rng(11)
 for n, W in ((61, 1500), (96, 700), (200, 2100)):
     anc = rng.integers(0, 2, size=W, dtype=np.uint8)
@@ -755,26 +756,52 @@ for n, W in ((61, 1500), (96, 700), (200, 2100)):
         for kind in ("match", "dice"):
             for fm in ("direct", "grouped"):
                 r = mat.pairwise_scan(wins, None, inA, inB, kind=kind, threshold=0.99, round_digits=4, fst_method=fm)
-                h.update(r.tobytes())
+                h.update(r.tobytes()); recs.append(r)
             for ww in (tiling, sliding):
-                h.update(mat.pairwise_scan(ww, None, inA, inB, kind=kind, threshold=0.995, round_digits=5).tobytes())
+                r = mat.pairwise_scan(ww, None, inA, inB, kind=kind, threshold=0.995, round_digits=5)
+                h.update(r.tobytes()); recs.append(r)
     h.update(bm.pairwise_counts(3, W - 1).tobytes())
     h.update(bm.pairwise_identity(0, W, "dice").tobytes()); h.update(bm.pairwise_identity(10, W, "match").tobytes())
     bm.set_site_weights(rng.integers(1, 40, size=W).astype(np.uint32))
     h.update(bm.pairwise_counts(0, W).tobytes())
     h.update(bm.pairwise_scan(wins[:2], None, inA, inB, kind="dice", threshold=0.98, round_digits=None).tobytes())
+np.save(sys.argv[1], np.concatenate(recs))
 print(h.hexdigest())
 """
-    # ... and the same for the other storage / scheduling choices of the all-pairs path that a caller must never see: counts as
-    # uint16 where they fit vs always int32, chains of windows per Gram ticket vs one window per ticket
-    outs = {}
-    for tag, extra in (("default", {}), ("no polarity", {"IMPOP_NO_POLARITY": "1"}), ("int32 counts", {"IMPOP_GRAM_U16": "0"}),
-                       ("no chains", {"IMPOP_GRAM_CHAIN": "1"}), ("long chains", {"IMPOP_GRAM_CHAIN": "8"})):
-        env = dict(os.environ, PYTHONPATH=ROOT, **extra)
-        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, cwd=ROOT, timeout=600)
-        assert r.returncode == 0, (tag, r.stderr[-2000:])
-        outs[tag] = r.stdout.strip()
-    assert len(outs["default"]) == 64 and len(set(outs.values())) == 1, outs
+    # ... and the same for the other storage / scheduling choices of the all-pairs path that a caller must never see: chains of
+    # windows per Gram ticket vs one window per ticket; counts as uint16 where they fit vs always int32.  The window-statistics
+    # kernels (stats_small.hip) take uint16 counts only: int32 counts go through the general epilogue kernels, whose sums run in
+    # another order — byte-identical to the default build with IMPOP_EPILOGUE_SMALL=0 (and to the general kernels without their
+    # compile-time variants, IMPOP_EPILOGUE_FAST=0), equal to the window-statistics kernels' records within the tolerance policy.
+    import tempfile
+    from conftest import stat_close
+    outs, recs = {}, {}
+    with tempfile.TemporaryDirectory() as td:
+        for tag, extra in (("default", {}), ("no polarity", {"IMPOP_NO_POLARITY": "1"}), ("no chains", {"IMPOP_GRAM_CHAIN": "1"}),
+                           ("long chains", {"IMPOP_GRAM_CHAIN": "8"}),
+                           ("general", {"IMPOP_EPILOGUE_SMALL": "0"}), ("general, int32 counts", {"IMPOP_GRAM_U16": "0"}),
+                           ("general, runtime variants", {"IMPOP_EPILOGUE_SMALL": "0", "IMPOP_EPILOGUE_FAST": "0"})):
+            env = dict(os.environ, PYTHONPATH=ROOT, **extra)
+            path = os.path.join(td, tag.replace(" ", "_").replace(",", "") + ".npy")
+            r = subprocess.run([sys.executable, "-c", code, path], capture_output=True, text=True, env=env, cwd=ROOT, timeout=600)
+            assert r.returncode == 0, (tag, r.stderr[-2000:])
+            outs[tag] = r.stdout.strip()
+            recs[tag] = np.load(path)
+    small = {outs[t] for t in ("default", "no polarity", "no chains", "long chains")}
+    general = {outs[t] for t in outs if t.startswith("general")}
+    assert len(outs["default"]) == 64 and len(small) == 1 and len(general) == 1, outs
+    a, b = recs["default"], recs["general"]
+    assert a.dtype == b.dtype and a.shape == b.shape
+    for name in a.dtype.names:
+        x, y = a[name], b[name]
+        if x.dtype.kind in "iu":
+            assert (x == y).all(), name
+            continue
+        for i in range(len(x)):
+            if np.isnan(x[i]) or np.isnan(y[i]):
+                assert np.isnan(x[i]) and np.isnan(y[i]), (name, i, x[i], y[i])
+            else:
+                assert stat_close(name, float(x[i]), float(y[i]), float(b["dxy"][i]) if "dxy" in a.dtype.names else 0.0), (name, i, x[i], y[i])
 
 
 def test_gram_exact_beyond_fp32_integer_range(ctx):

@@ -11,7 +11,7 @@ import csv, glob, sys, collections
 f = sorted(glob.glob(sys.argv[1] + "/prof/**/p_kernel_trace.csv", recursive=True))[-1]
 per = collections.defaultdict(list)
 for r in csv.DictReader(open(f)):
-    name = r["Kernel_Name"].split("(")[0].replace("impop::", "").replace("void ", "")
+    name = r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0].replace("impop::", "").replace("void ", "")
     per[name].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6)
 for k, v in sorted(per.items(), key=lambda kv: -sum(kv[1])):
     if sum(v) > 0.5:

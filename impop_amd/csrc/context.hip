@@ -39,6 +39,22 @@ int ctx_scratch(impop_ctx *ctx, size_t bytes, void **out) {
     return IMPOP_OK;
 }
 
+int ctx_pinned(impop_ctx *ctx, size_t bytes, void **out) {
+    if (bytes > ctx->pinned_bytes) {
+        if (ctx->pinned) {
+            HIP_TRY(hipStreamSynchronize(ctx->stream));
+            HIP_TRY(hipHostFree(ctx->pinned));
+            ctx->pinned = nullptr;
+            ctx->pinned_bytes = 0;
+        }
+        const size_t want = bytes + (bytes >> 2) + 4096;
+        HIP_TRY(hipHostMalloc(&ctx->pinned, want, hipHostMallocDefault));
+        ctx->pinned_bytes = want;
+    }
+    *out = ctx->pinned;
+    return IMPOP_OK;
+}
+
 int ctx_aux(impop_ctx *ctx, int slot, size_t bytes, void **out) {
     if (bytes > ctx->aux_bytes[slot]) {
         HIP_TRY(hipStreamSynchronize(ctx->stream));
@@ -144,6 +160,7 @@ IMPOP_API int impop_ctx_destroy(impop_ctx *ctx) {
     if (ctx->d_err) hipFree(ctx->d_err);
     for (auto &e : ctx->gram_events) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
     if (ctx->scratch) hipFree(ctx->scratch);
+    if (ctx->pinned) hipHostFree(ctx->pinned);
     for (void *a : ctx->d_aux)
         if (a) hipFree(a);
     if (ctx->side) { hipStreamSynchronize(ctx->side); hipStreamDestroy(ctx->side); }

@@ -103,6 +103,11 @@ struct impop_ctx {
     // growable scratch
     void *scratch = nullptr;
     size_t scratch_bytes = 0;
+    // growable PINNED host staging (context.hip ctx_pinned): per-chunk metadata up and records down of impop_pairwise_scan —
+    // from pageable memory either copy is a host memcpy into the runtime's own staging buffer first (0.8 MB up before the Gram
+    // kernel can start, 0.4 MB down after the last kernel, per 4096 windows)
+    void *pinned = nullptr;
+    size_t pinned_bytes = 0;
     // growable side buffers of the epilogue kernels that split large problems over several workgroups (stats.hip):
     // slot 0 h-fst partial sums, slot 1 pica2 group tables + row sums; separate because the two run side by side
     void *d_aux[2] = {nullptr, nullptr};
@@ -155,6 +160,7 @@ struct impop_matrix {
 
 namespace impop {
 int ctx_scratch(impop_ctx *ctx, size_t bytes, void **out);
+int ctx_pinned(impop_ctx *ctx, size_t bytes, void **out);  // host, page-locked, grow-only; valid until the next larger request
 int ctx_err_fetch(impop_ctx *ctx);                 // enqueue its copy to the host (before the call's own stream sync)
 int ctx_err_result(impop_ctx *ctx, const char *fn);  // after that sync: IMPOP_OK, or IMPOP_E_INTERNAL (word cleared, message set)
 constexpr uint32_t DEV_ERR_GROUPING = 1u;            // greedy_groups_bits ran out of its progress bound

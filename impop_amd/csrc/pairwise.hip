@@ -1451,8 +1451,9 @@ IMPOP_API int impop_pairwise_scan(impop_ctx *ctx, const impop_matrix *m, const i
     lap("cells");
     const size_t gram_bytes = (size_t)ld * ld * 4;
     uint64_t cap = ((plane_buffer ? 2ull : 4ull) << 30) / gram_bytes;
-    if (cap < 1) cap = 1;
     if (cap > 4096) cap = 4096;
+    cap = std::min<uint64_t>(cap, std::max<uint64_t>(cells.size(), n_windows));  // a short call stages (and copies) short tables
+    if (cap < 1) cap = 1;
     void *d = nullptr;
     const size_t need = 4096 + cap * ((plane_buffer ? 2 : 1) * gram_bytes + sizeof(GramWindow) + 24 + sizeof(Pica2Out) + sizeof(HfstOut) +
                                       sizeof(impop_window_stats) + sizeof(impop_pairwise_stats) + 2 * sizeof(GramWindow) + 4 + 3584) + 16 * 256 +
@@ -1494,15 +1495,13 @@ IMPOP_API int impop_pairwise_scan(impop_ctx *ctx, const impop_matrix *m, const i
     PW_TRY(hipMemcpyAsync(d_fb, fb.data(), n, hipMemcpyHostToDevice, ctx->stream));
     if (!ia.empty()) PW_TRY(hipMemcpyAsync(d_ia, ia.data(), ia.size() * 4, hipMemcpyHostToDevice, ctx->stream));
     if (!ib.empty()) PW_TRY(hipMemcpyAsync(d_ib, ib.data(), ib.size() * 4, hipMemcpyHostToDevice, ctx->stream));
-    std::vector<impop_window_stats> scan_host(n_windows);
+    std::vector<impop_window_stats> scan_host;  // only with a scan plan; else the records are n_sites and zeros (S: the device fills it in)
     if (plan) {
+        scan_host.resize(n_windows);
         rc = impop_scan_plan_launch(plan, nullptr);
         if (rc) return fail(rc);
         rc = impop_scan_plan_fetch(plan, scan_host.data());
         if (rc) return fail(rc);
-    } else {  // no S wanted, or S from the site bitmap (filled in on the device per chunk)
-        memset(scan_host.data(), 0, n_windows * sizeof(impop_window_stats));
-        for (uint64_t i = 0; i < n_windows; ++i) scan_host[i].n_sites = (uint32_t)window_W(m, windows[i].site_begin, windows[i].site_end);
     }
     // even out the chunks: a total slightly above the capacity would otherwise leave a last chunk of a few
     // windows whose single-workgroup epilogue kernels cost their full latency
@@ -1515,13 +1514,19 @@ IMPOP_API int impop_pairwise_scan(impop_ctx *ctx, const impop_matrix *m, const i
         cell_limit = std::min<uint64_t>(cap, (cells.size() + n_chunks - 1) / n_chunks + widest);
     }
     lap("scratch + scan_host");
-    std::vector<char> hmeta(meta_bytes, 0);
-    GramWindow *gw = reinterpret_cast<GramWindow *>(hmeta.data() + o_w), *swv = reinterpret_cast<GramWindow *>(hmeta.data() + o_sw),
-               *owv = reinterpret_cast<GramWindow *>(hmeta.data() + o_ow);
-    uint64_t *Wv = reinterpret_cast<uint64_t *>(hmeta.data() + o_W), *Lv = reinterpret_cast<uint64_t *>(hmeta.data() + o_L);
-    uint32_t *fv = reinterpret_cast<uint32_t *>(hmeta.data() + o_first), *cvv = reinterpret_cast<uint32_t *>(hmeta.data() + o_count);
-    impop_window_stats *sv = reinterpret_cast<impop_window_stats *>(hmeta.data() + o_s);
-    std::vector<impop_pairwise_stats> ov(cap);
+    // page-locked staging for the metadata going up and the records coming down (ctx_pinned)
+    const size_t out_off = up256(meta_bytes);
+    void *pin = nullptr;
+    rc = ctx_pinned(ctx, out_off + cap * sizeof(impop_pairwise_stats), &pin);
+    if (rc) return fail(rc);
+    char *hmeta = reinterpret_cast<char *>(pin);
+    memset(hmeta, 0, meta_bytes);
+    GramWindow *gw = reinterpret_cast<GramWindow *>(hmeta + o_w), *swv = reinterpret_cast<GramWindow *>(hmeta + o_sw),
+               *owv = reinterpret_cast<GramWindow *>(hmeta + o_ow);
+    uint64_t *Wv = reinterpret_cast<uint64_t *>(hmeta + o_W), *Lv = reinterpret_cast<uint64_t *>(hmeta + o_L);
+    uint32_t *fv = reinterpret_cast<uint32_t *>(hmeta + o_first), *cvv = reinterpret_cast<uint32_t *>(hmeta + o_count);
+    impop_window_stats *sv = reinterpret_cast<impop_window_stats *>(hmeta + o_s);
+    impop_pairwise_stats *ov = reinterpret_cast<impop_pairwise_stats *>(hmeta + out_off);
     std::vector<uint32_t> add_h;
     uint64_t call_max_W = 0;  // bounds every Gram count of the call (a cell is a window or a piece of one; compacted: + its constant)
     for (uint64_t i = 0; i < n_windows; ++i) call_max_W = std::max(call_max_W, window_W(m, windows[i].site_begin, windows[i].site_end));
@@ -1560,7 +1565,8 @@ IMPOP_API int impop_pairwise_scan(impop_ctx *ctx, const impop_matrix *m, const i
             Lv[k] = windows[wdx].seq_len;
             fv[k] = count[wdx] ? first[wdx] - c_lo : 0;
             cvv[k] = count[wdx];
-            sv[k] = scan_host[wdx];
+            if (plan) sv[k] = scan_host[wdx];
+            else { memset(&sv[k], 0, sizeof(sv[k])); sv[k].n_sites = (uint32_t)Wv[k]; }
             swv[k] = {mw[wdx].site_begin, mw[wdx].site_end};
             owv[k] = {windows[wdx].site_begin, windows[wdx].site_end};
         }
@@ -1568,7 +1574,7 @@ IMPOP_API int impop_pairwise_scan(impop_ctx *ctx, const impop_matrix *m, const i
         bool one_to_one = true;
         for (uint64_t k = 0; k < cnt && one_to_one; ++k) one_to_one = cvv[k] == 1 && fv[k] == k;
         lap("chunk metadata");
-        PW_TRY(hipMemcpyAsync(d_meta, hmeta.data(), meta_bytes, hipMemcpyHostToDevice, ctx->stream));
+        PW_TRY(hipMemcpyAsync(d_meta, hmeta, meta_bytes, hipMemcpyHostToDevice, ctx->stream));
         if (use_segmap) {
             hipLaunchKernelGGL(seg_count_kernel, dim3((uint32_t)((cnt + 3) / 4)), dim3(256), 0, ctx->stream, m->d_segmap, d_sw, cnt, d_s,
                                (uint32_t *)nullptr);
@@ -1649,7 +1655,7 @@ IMPOP_API int impop_pairwise_scan(impop_ctx *ctx, const impop_matrix *m, const i
                            want_s ? nP : 0u, params->d_pi_mode, want_s ? params->s_scope : 0, ctx->d_taj, d_o);
         PW_TRY(hipGetLastError());
         lap("chunk launched");
-        PW_TRY(hipMemcpyAsync(ov.data(), d_o, cnt * sizeof(impop_pairwise_stats), hipMemcpyDeviceToHost, ctx->stream));
+        PW_TRY(hipMemcpyAsync(ov, d_o, cnt * sizeof(impop_pairwise_stats), hipMemcpyDeviceToHost, ctx->stream));
         rc = ctx_err_fetch(ctx);
         if (rc) return fail(rc);
         PW_TRY(hipStreamSynchronize(ctx->stream));  // the staging vectors are reused by the next chunk

@@ -50,6 +50,58 @@ __device__ __forceinline__ double ident_of(const SimView &S, const double *tbl, 
     return (uint32_t)H < SIM_TBL_N ? tbl[H] : match_identity(S.W, (int64_t)H, S.round_digits);
 }
 
+// The counts of a batch of U rows: I[u][k] = the problem's I(row u, this lane's position in word k), for the words k0[u] .. nw a row
+// needs (the others keep a value nobody reads).  off(u, k) = element offset of that entry in a Gram matrix.
+//  one matrix per problem (SEG false): all loads of the batch go out before the first is consumed;
+//  a problem that is the SUM of nseg consecutive matrices (sliding windows sharing elementary segments, stats_kernels.h SimBatch):
+//  row by row, two segments' loads in flight, added up once both have been issued (nseg == 0: the counts are 0).
+template <uint32_t NWK, int U, bool SEG, class OFF>
+__device__ __forceinline__ void row_counts(const uint16_t *__restrict__ g, uint32_t nseg, uint32_t sstride, const bool (&lv)[U],
+                                           const uint32_t (&k0)[U], uint32_t nw, int32_t junk, OFF off, int32_t (&I)[U][NWK]) {
+    if (!SEG) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+#pragma unroll
+            for (uint32_t k = 0; k < NWK; ++k) {
+                I[u][k] = junk;  // see skipped_load
+                if (lv[u] && k >= k0[u] && k < nw) I[u][k] = (int32_t)g[off(u, k)];
+            }
+        }
+    } else {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+#pragma unroll
+            for (uint32_t k = 0; k < NWK; ++k) I[u][k] = 0;
+            if (!lv[u]) continue;
+            for (uint32_t s0 = 0; s0 < nseg; s0 += 2) {
+                const bool two = s0 + 1 < nseg;
+                const uint32_t b0 = s0 * sstride, b1 = (two ? s0 + 1 : s0) * sstride;
+                int32_t T0[NWK], T1[NWK];
+#pragma unroll
+                for (uint32_t k = 0; k < NWK; ++k) {
+                    T0[k] = junk; T1[k] = junk;
+                    if (k >= k0[u] && k < nw) {
+                        const uint32_t o = off(u, k);
+                        T0[k] = (int32_t)g[b0 + o];
+                        if (two) T1[k] = (int32_t)g[b1 + o];
+                    }
+                }
+#pragma unroll
+                for (uint32_t k = 0; k < NWK; ++k)
+                    if (k >= k0[u] && k < nw) I[u][k] += T0[k] + (two ? T1[k] : 0);
+            }
+        }
+    }
+}
+// one entry of the problem (all segments)
+template <bool SEG>
+__device__ __forceinline__ int32_t one_count(const uint16_t *__restrict__ g, uint32_t nseg, uint32_t sstride, uint32_t off) {
+    if (!SEG) return (int32_t)g[off];
+    int32_t v = 0;
+    for (uint32_t s = 0; s < nseg; ++s) v += (int32_t)g[s * sstride + off];
+    return v;
+}
+
 // "identity > threshold" is "H <= H*" (stats.hip match_cutoff: the largest H whose identity — the very function the pairs
 // would be tested with — exceeds the threshold; -1: none).  One wave searches 64 distances at a time: three rounds for a
 // 50 kb window instead of seventeen bisection steps every thread repeats.
@@ -79,7 +131,7 @@ __device__ __forceinline__ int32_t match_cutoff_wave(const SimView &S, double th
 // visited once as (list index q, list index p > q): q < na, p < na is a pair inside A, q < na <= p a pair between, na <= q a
 // pair inside B.  Lane L owns list indices L, L + 64, ...; a wave takes rows q and the words of the list right of them.
 // NWK words of the list (4: up to 256 members, 8: up to 512), U rows in flight — U * NWK = 16 loads either way.
-template <uint32_t NWK, int U>
+template <uint32_t NWK, int U, bool SEG>
 __device__ __forceinline__ void hfst_small_rows(const SimView &S, const double *tbl, const uint16_t *__restrict__ g, uint32_t ld, uint32_t wave,
                                                 uint32_t lane, uint32_t na, uint32_t nmem, uint32_t nw, const uint16_t *mpos,
                                                 const int32_t *dg_l, double &accA, double &accB, double &accX) {
@@ -109,7 +161,7 @@ __device__ __forceinline__ void hfst_small_rows(const SimView &S, const double *
     }
     const uint32_t nrows = nmem > wave ? (nmem - wave + SM_T / 64 - 1) / (SM_T / 64) : 0;
     for (uint32_t r0 = 0; r0 < nrows; r0 += U) {
-        uint32_t q[U], k0[U];
+        uint32_t q[U], k0[U], pr[U];
         int32_t ar[U];
         bool lv[U];
         int32_t I[U][NWK];
@@ -119,23 +171,17 @@ __device__ __forceinline__ void hfst_small_rows(const SimView &S, const double *
             const uint32_t r = lv[u] ? r0 + u : r0;
             q[u] = wave + (SM_T / 64) * r;
             k0[u] = q[u] >> 6;
-            uint32_t pr;
             if (NT == 1 || r < 64) {
-                pr = (uint32_t)__builtin_amdgcn_readlane((int)prow[0], (int)(r & 63));
+                pr[u] = (uint32_t)__builtin_amdgcn_readlane((int)prow[0], (int)(r & 63));
                 ar[u] = __builtin_amdgcn_readlane(arow[0], (int)(r & 63));
             } else {
-                pr = (uint32_t)__builtin_amdgcn_readlane((int)prow[NT - 1], (int)(r & 63));
+                pr[u] = (uint32_t)__builtin_amdgcn_readlane((int)prow[NT - 1], (int)(r & 63));
                 ar[u] = __builtin_amdgcn_readlane(arow[NT - 1], (int)(r & 63));
             }
-#pragma unroll
-            for (uint32_t k = 0; k < NWK; ++k) {
-                I[u][k] = junk;
-                if (lv[u] && k >= k0[u] && k < nw) {  // uniform; the pair's entry in the upper triangle (the part the Gram kernel writes)
-                    const uint32_t mn = pr < pos[k] ? pr : pos[k], mx = pr < pos[k] ? pos[k] : pr;
-                    I[u][k] = (int32_t)g[mn * ld + mx];
-                }
-            }
         }
+        // the pair's entry in the upper triangle (the part the Gram kernel writes)
+        row_counts<NWK, U, SEG>(g, S.nseg, (uint32_t)S.seg_stride, lv, k0, nw, junk,
+                                [&](int u, uint32_t k) { return (pr[u] < pos[k] ? pr[u] : pos[k]) * ld + (pr[u] < pos[k] ? pos[k] : pr[u]); }, I);
 #pragma unroll
         for (int u = 0; u < U; ++u) {
 #pragma unroll
@@ -156,7 +202,8 @@ __device__ __forceinline__ void hfst_small_rows(const SimView &S, const double *
     }
 }
 
-__global__ __launch_bounds__(SM_T, 5) void hfst_small_kernel(SimBatch batch, const uint8_t *__restrict__ in_a,
+template <bool SEG>
+__global__ __launch_bounds__(SM_T, SEG ? 4 : 5) void hfst_small_kernel(SimBatch batch, const uint8_t *__restrict__ in_a,
                                                              const uint8_t *__restrict__ in_b, const uint64_t *__restrict__ seq_len,
                                                              HfstOut *__restrict__ out) {
     __shared__ double tbl[SIM_TBL_N];
@@ -167,7 +214,8 @@ __global__ __launch_bounds__(SM_T, 5) void hfst_small_kernel(SimBatch batch, con
     __shared__ double shd[SM_T / 64];
     const uint64_t prob = blockIdx.x;
     SimView S = sim_view(batch, prob);
-    S.dense = nullptr; S.nseg = 1; S.g16 = 1;
+    S.dense = nullptr; S.g16 = 1;
+    if (!SEG) S.nseg = 1;
     const uint32_t n = batch.n, tid = threadIdx.x, lane = tid & 63, wave = uni(tid >> 6), ld = S.ld;
     const uint16_t *__restrict__ g = reinterpret_cast<const uint16_t *>(S.gram);
     for (uint32_t i = tid; i < SM_N; i += SM_T) {  // (one round of loads for the workgroup; read one by one by the listing wave
@@ -197,11 +245,11 @@ __global__ __launch_bounds__(SM_T, 5) void hfst_small_kernel(SimBatch batch, con
     }
     __syncthreads();
     const uint32_t na = uni(sh_na), nb = uni(sh_nb), nmem = na + nb, nw = (nmem + 63) >> 6;
-    for (uint32_t p = tid; p < nmem; p += SM_T) dg_l[p] = (int32_t)g[(uint32_t)mpos[p] * (ld + 1)];
+    for (uint32_t p = tid; p < nmem; p += SM_T) dg_l[p] = one_count<SEG>(g, S.nseg, (uint32_t)S.seg_stride, (uint32_t)mpos[p] * (ld + 1));
     __syncthreads();
     double accA = 0.0, accB = 0.0, accX = 0.0;
-    if (nw <= 4) hfst_small_rows<4, 4>(S, tbl, g, ld, wave, lane, na, nmem, nw, mpos, dg_l, accA, accB, accX);
-    else hfst_small_rows<8, 2>(S, tbl, g, ld, wave, lane, na, nmem, nw, mpos, dg_l, accA, accB, accX);
+    if (nw <= 4) hfst_small_rows<4, 4, SEG>(S, tbl, g, ld, wave, lane, na, nmem, nw, mpos, dg_l, accA, accB, accX);
+    else hfst_small_rows<8, 2, SEG>(S, tbl, g, ld, wave, lane, na, nmem, nw, mpos, dg_l, accA, accB, accX);
     accA = block_sum(accA, shd); accB = block_sum(accB, shd); accX = block_sum(accX, shd);
     if (tid == 0) {
         const uint64_t a_ = na, b_ = nb;  // every pair is present on a Gram problem: the counts are the class sizes' products
@@ -221,7 +269,8 @@ __global__ __launch_bounds__(SM_T, 5) void hfst_small_kernel(SimBatch batch, con
 //  (row AND free), the candidates it absorbed drop out, and so on.
 //  Step 2-3: up to 64 groups a thread per representative pair; beyond, a wave per representative row against a
 //  per-position frequency (0 where the position represents nothing), identities from the Hamming-distance memo.
-__global__ __launch_bounds__(SM_T, 5) void pica2_small_kernel(SimBatch batch, const uint32_t *__restrict__ idx, uint32_t m, double thr,
+template <bool SEG>
+__global__ __launch_bounds__(SM_T, SEG ? 4 : 5) void pica2_small_kernel(SimBatch batch, const uint32_t *__restrict__ idx, uint32_t m, double thr,
                                                               const uint64_t *__restrict__ seq_len, Pica2Out *__restrict__ out) {
     __shared__ double tbl[SIM_TBL_N];
     __shared__ double fpos[SM_N];
@@ -233,7 +282,9 @@ __global__ __launch_bounds__(SM_T, 5) void pica2_small_kernel(SimBatch batch, co
     __shared__ double shd[SM_T / 64];
     const uint64_t prob = blockIdx.x;
     SimView S = sim_view(batch, prob);
-    S.dense = nullptr; S.nseg = 1; S.g16 = 1;
+    S.dense = nullptr; S.g16 = 1;
+    if (!SEG) S.nseg = 1;
+    const uint32_t nseg = S.nseg, sstride = (uint32_t)S.seg_stride;
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = uni(tid >> 6), ld = S.ld;
     const uint16_t *__restrict__ g = reinterpret_cast<const uint16_t *>(S.gram);
     const int32_t junk = (int32_t)lane;  // see skipped_load
@@ -241,7 +292,7 @@ __global__ __launch_bounds__(SM_T, 5) void pica2_small_kernel(SimBatch batch, co
     for (uint32_t o = tid; o < SM_N; o += SM_T) {
         const uint32_t e = o < m ? (idx ? idx[o] : o) : 0u;
         epos[o] = (uint16_t)e;
-        dg_l[o] = o < m ? (int32_t)g[e * (ld + 1)] : 0;
+        dg_l[o] = o < m ? one_count<SEG>(g, nseg, sstride, e * (ld + 1)) : 0;
     }
     if (wave == 0) {
         const int32_t hc = match_cutoff_wave(S, thr);
@@ -306,7 +357,7 @@ __global__ __launch_bounds__(SM_T, 5) void pica2_small_kernel(SimBatch batch, co
             if (b < nb) { cst = cand[b]; acst = dg_l[cst]; rowst = (uint32_t)epos[cst] * ld; }
         }
         for (uint32_t b0 = wave, j0 = 0; b0 < nb; b0 += 2 * (SM_T / 64), j0 += 2) {
-            uint32_t c[2], k0[2];
+            uint32_t c[2], k0[2], row[2];
             int32_t ac[2];
             bool lv[2];
             int32_t I[2][SM_W];
@@ -318,13 +369,10 @@ __global__ __launch_bounds__(SM_T, 5) void pica2_small_kernel(SimBatch batch, co
                 c[u] = (uint32_t)__builtin_amdgcn_readlane((int)cst, (int)j);
                 k0[u] = c[u] >> 6;
                 ac[u] = __builtin_amdgcn_readlane(acst, (int)j);
-                const uint32_t row = (uint32_t)__builtin_amdgcn_readlane((int)rowst, (int)j);
-#pragma unroll
-                for (uint32_t k = 0; k < SM_W; ++k) {
-                    I[u][k] = junk;
-                    if (lv[u] && k >= k0[u] && k < nw) I[u][k] = (int32_t)g[row + ek[k]];  // positions ascend, so do the elements
-                }
+                row[u] = (uint32_t)__builtin_amdgcn_readlane((int)rowst, (int)j);
             }
+            // positions ascend, so do the elements: (row, column) is in the upper triangle
+            row_counts<SM_W, 2, SEG>(g, nseg, sstride, lv, k0, nw, junk, [&](int u, uint32_t k) { return row[u] + ek[k]; }, I);
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 const uint32_t b = b0 + (SM_T / 64) * u;
@@ -419,7 +467,7 @@ __global__ __launch_bounds__(SM_T, 5) void pica2_small_kernel(SimBatch batch, co
         }
         const uint32_t nrows = G > wave ? (G - wave + SM_T / 64 - 1) / (SM_T / 64) : 0;
         for (uint32_t r0 = 0; r0 < nrows; r0 += 2) {
-            uint32_t rr[2], k0[2];
+            uint32_t rr[2], k0[2], row[2];
             int32_t ar[2];
             bool lv[2];
             int32_t I[2][SM_W];
@@ -430,14 +478,10 @@ __global__ __launch_bounds__(SM_T, 5) void pica2_small_kernel(SimBatch batch, co
                 const uint32_t t = r >> 6, j = r & 63;
                 rr[u] = (uint32_t)__builtin_amdgcn_readlane((int)(t ? rrs[1] : rrs[0]), (int)j);
                 ar[u] = __builtin_amdgcn_readlane(t ? ars[1] : ars[0], (int)j);
-                const uint32_t row = (uint32_t)__builtin_amdgcn_readlane((int)(t ? rows_[1] : rows_[0]), (int)j);
+                row[u] = (uint32_t)__builtin_amdgcn_readlane((int)(t ? rows_[1] : rows_[0]), (int)j);
                 k0[u] = rr[u] >> 6;
-#pragma unroll
-                for (uint32_t k = 0; k < SM_W; ++k) {
-                    I[u][k] = junk;
-                    if (lv[u] && k >= k0[u] && k < nw) I[u][k] = (int32_t)g[row + ek[k]];
-                }
             }
+            row_counts<SM_W, 2, SEG>(g, nseg, sstride, lv, k0, nw, junk, [&](int u, uint32_t k) { return row[u] + ek[k]; }, I);
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 if (!lv[u]) continue;
@@ -463,7 +507,7 @@ __global__ __launch_bounds__(SM_T, 5) void pica2_small_kernel(SimBatch batch, co
             const uint32_t a = t / G, b = t - a * G;
             if (a >= b) continue;
             const uint32_t ra = rep[a], rb = rep[b];  // ra < rb: the groups are numbered by their seeds, which ascend
-            const int32_t H = dg_l[ra] + dg_l[rb] - 2 * (int32_t)g[(uint32_t)epos[ra] * ld + epos[rb]];
+            const int32_t H = dg_l[ra] + dg_l[rb] - 2 * one_count<SEG>(g, nseg, sstride, (uint32_t)epos[ra] * ld + epos[rb]);
             const double s = match_identity(S.W, (int64_t)H, S.round_digits);
             acc += ((1 - s) * ((double)gsz[a] / total)) * ((double)gsz[b] / total);
         }
@@ -485,7 +529,8 @@ __global__ __launch_bounds__(SM_T, 5) void pica2_small_kernel(SimBatch batch, co
 
 bool small_shape(const SimBatch &b) {
     static const bool off = [] { const char *e = getenv("IMPOP_EPILOGUE_SMALL"); return e && e[0] == '0'; }();  // A/B and test switch
-    return !off && b.gram && !b.dense && b.g16 && !b.seg_first && !b.seg_count && b.kind == IMPOP_IDENTITY_MATCH && b.ld <= 65535;
+    return !off && b.gram && !b.dense && b.g16 && (b.seg_first != nullptr) == (b.seg_count != nullptr) && b.kind == IMPOP_IDENTITY_MATCH &&
+           b.ld <= 4096;  // (element offsets are 32-bit: a problem's segments, at most a few thousand matrices of ld x ld, stay below 2^32)
 }
 
 }  // namespace
@@ -499,15 +544,22 @@ int launch_pica2_small(impop_ctx *ctx, const SimBatch &b, uint64_t n_problems, c
                        const uint64_t *d_seq_len, Pica2Out *d_out) {
     SimBatch be = b;
     be.err = ctx->d_err;
-    hipLaunchKernelGGL(pica2_small_kernel, dim3((uint32_t)n_problems), dim3(SM_T), 0, ctx->stream, be, d_idx, n_el, threshold, d_seq_len,
-                       d_out);
+    if (b.seg_first)
+        hipLaunchKernelGGL(pica2_small_kernel<true>, dim3((uint32_t)n_problems), dim3(SM_T), 0, ctx->stream, be, d_idx, n_el, threshold,
+                           d_seq_len, d_out);
+    else
+        hipLaunchKernelGGL(pica2_small_kernel<false>, dim3((uint32_t)n_problems), dim3(SM_T), 0, ctx->stream, be, d_idx, n_el, threshold,
+                           d_seq_len, d_out);
     HIP_TRY(hipGetLastError());
     return IMPOP_OK;
 }
 
 int launch_hfst_small(impop_ctx *ctx, const SimBatch &b, uint64_t n_problems, const uint8_t *d_in_a, const uint8_t *d_in_b,
                       const uint64_t *d_seq_len, HfstOut *d_out) {
-    hipLaunchKernelGGL(hfst_small_kernel, dim3((uint32_t)n_problems), dim3(SM_T), 0, ctx->stream, b, d_in_a, d_in_b, d_seq_len, d_out);
+    if (b.seg_first)
+        hipLaunchKernelGGL(hfst_small_kernel<true>, dim3((uint32_t)n_problems), dim3(SM_T), 0, ctx->stream, b, d_in_a, d_in_b, d_seq_len, d_out);
+    else
+        hipLaunchKernelGGL(hfst_small_kernel<false>, dim3((uint32_t)n_problems), dim3(SM_T), 0, ctx->stream, b, d_in_a, d_in_b, d_seq_len, d_out);
     HIP_TRY(hipGetLastError());
     return IMPOP_OK;
 }

@@ -1712,3 +1712,48 @@ def test_bit_matrix_grouping_beyond_4096_elements(ctx, oracle):
     r = bm.pairwise_scan([(0, W, W)], None, None, None, threshold=0.995, round_digits=None, s_scope=2)[0]
     assert int(r["n_groups"]) == oracle.pica2(sim, 0.995, W, None)[3]
     bm.free()
+
+
+def test_window_statistics_kernels_edge_shapes(ctx, oracle):
+    """csrc/stats_small.hip (pica2 / h-fst on disjoint and sliding windows of <= 512 haplotypes, `match`, uint16 counts): sizes around the
+    64-position words and the 256-member switch of the h-fst rows, element lists (subset P), overlapping / empty / one-member
+    populations, thresholds from "one group" (-1) to "nobody joins" (1.5), roundings 0..6 — every field against the oracle
+    (tools/soak_small.py is the long-running form)."""
+    from conftest import stat_close
+    rng = np.random.default_rng(404)
+    sizes = [1, 2, 3, 63, 64, 65, 127, 128, 129, 255, 256, 257, 300, 465, 511, 512]
+    thrs = [1.5, 1.0, 0.9999, 0.999, 0.99, 0.9, 0.0, -1.0]
+    for it, n in enumerate(sizes * 2):
+        nwin = (1, 3, 9)[it % 3]
+        wlen = int(rng.integers(40, 700))
+        step = wlen if it < len(sizes) else max(1, wlen // (2, 3, 5)[it % 3])  # second round: sliding windows (segment sums)
+        W = (nwin - 1) * step + wlen + int(rng.integers(0, 50))
+        nf = int(rng.integers(1, 30))
+        f = (rng.random((nf, W)) < 0.5).astype(np.uint8)
+        m = f[rng.integers(0, nf, size=n)] ^ (rng.random((n, W)) < rng.choice([0.0, 0.0005, 0.003, 0.02])).astype(np.uint8)
+        bits = oracle.pack_hap_major(m)
+        bm = ctx.upload_dense(m, keep_hap_major=True)
+        if it % 4 == 3:
+            bm = bm.compact()
+        wins = [(k * step, k * step + wlen, (0, wlen, 50000)[(it + k) % 3]) for k in range(nwin)]
+        thr = thrs[it % len(thrs)]
+        rd = None if it % 5 == 0 else it % 7
+        inP = None if it % 2 == 0 else (rng.random(n) < (0.05, 0.5, 0.9)[it % 3]).astype(np.uint8)
+        inA = (rng.random(n) < (0.0, 0.02, 0.3, 0.5, 1.0)[it % 5]).astype(np.uint8)
+        inB = (rng.random(n) < (0.5, 0.3, 1.0, 0.02, 0.0)[it % 5]).astype(np.uint8)
+        if it % 3 == 1:
+            inB &= ~inA & 1
+        res = bm.pairwise_scan(wins, inP, inA, inB, kind="match", threshold=thr, round_digits=rd, s_scope=2)
+        sel = np.arange(n) if inP is None else np.nonzero(inP)[0]
+        for (a, b, L), r in zip(wins, res):
+            sim = oracle.identity(oracle.pairwise_counts(bits, n, a, b), b - a, 0)
+            pi, ps, _, G = oracle.pica2(sim[np.ix_(sel, sel)], thr, L if L else None, rd)
+            what = (n, W, (a, b, L), thr, rd)
+            assert int(r["n_groups"]) == G, what
+            for k, v in (("pi", pi), ("pi_site", ps)):
+                got = float(r[k])
+                assert (got != got and v != v) or rel_close(got, v, REL, 0.0), what + (k, got, v)
+            h, _ = oracle.hfst(sim, inA, inB, L if L else None, rd)
+            for k, v in h.items():
+                assert stat_close(k, float(r[k]), v, h["dxy"]), what + (k, float(r[k]), v)
+        bm.free()

@@ -1559,27 +1559,9 @@ IMPOP_API int impop_pairwise_scan(impop_ctx *ctx, const impop_matrix *m, const i
             gw[c] = {cells[c_lo + c].b, cells[c_lo + c].e};
             max_sites = std::max<uint64_t>(max_sites, cells[c_lo + c].e - cells[c_lo + c].b);
         }
-        for (uint64_t k = 0; k < cnt; ++k) {
-            const uint64_t wdx = ord[base + k];
-            Wv[k] = window_W(m, windows[wdx].site_begin, windows[wdx].site_end);
-            Lv[k] = windows[wdx].seq_len;
-            fv[k] = count[wdx] ? first[wdx] - c_lo : 0;
-            cvv[k] = count[wdx];
-            if (plan) sv[k] = scan_host[wdx];
-            else { memset(&sv[k], 0, sizeof(sv[k])); sv[k].n_sites = (uint32_t)Wv[k]; }
-            swv[k] = {mw[wdx].site_begin, mw[wdx].site_end};
-            owv[k] = {windows[wdx].site_begin, windows[wdx].site_end};
-        }
-        // problem k IS Gram matrix k (disjoint windows, none empty): the epilogue kernels then take their one-matrix variants
-        bool one_to_one = true;
-        for (uint64_t k = 0; k < cnt && one_to_one; ++k) one_to_one = cvv[k] == 1 && fv[k] == k;
-        lap("chunk metadata");
-        PW_TRY(hipMemcpyAsync(d_meta, hmeta, meta_bytes, hipMemcpyHostToDevice, ctx->stream));
-        if (use_segmap) {
-            hipLaunchKernelGGL(seg_count_kernel, dim3((uint32_t)((cnt + 3) / 4)), dim3(256), 0, ctx->stream, m->d_segmap, d_sw, cnt, d_s,
-                               (uint32_t *)nullptr);
-            PW_TRY(hipGetLastError());
-        }
+        // the Gram launch needs the cells alone: they go up first and the kernel starts, the per-window tables are filled in (and
+        // copied) while it runs
+        if (n_cells) PW_TRY(hipMemcpyAsync(d_meta + o_w, hmeta + o_w, (size_t)n_cells * sizeof(GramWindow), hipMemcpyHostToDevice, ctx->stream));
         if (n_cells) {
             hipEvent_t ev1 = nullptr;
             if (ctx->gram_timing) {  // impop_ctx_gram_timing: the Gram launch(es) of this chunk between two events
@@ -1603,6 +1585,27 @@ IMPOP_API int impop_pairwise_scan(impop_ctx *ctx, const impop_matrix *m, const i
                 rc = launch_gram_unflip(ctx, m, d_g, n_cells, g16);
                 if (rc) return fail(rc);
             }
+        }
+        for (uint64_t k = 0; k < cnt; ++k) {
+            const uint64_t wdx = ord[base + k];
+            Wv[k] = window_W(m, windows[wdx].site_begin, windows[wdx].site_end);
+            Lv[k] = windows[wdx].seq_len;
+            fv[k] = count[wdx] ? first[wdx] - c_lo : 0;
+            cvv[k] = count[wdx];
+            if (plan) sv[k] = scan_host[wdx];
+            else { memset(&sv[k], 0, sizeof(sv[k])); sv[k].n_sites = (uint32_t)Wv[k]; }
+            swv[k] = {mw[wdx].site_begin, mw[wdx].site_end};
+            owv[k] = {windows[wdx].site_begin, windows[wdx].site_end};
+        }
+        // problem k IS Gram matrix k (disjoint windows, none empty): the epilogue kernels then take their one-matrix variants
+        bool one_to_one = true;
+        for (uint64_t k = 0; k < cnt && one_to_one; ++k) one_to_one = cvv[k] == 1 && fv[k] == k;
+        lap("chunk metadata");
+        PW_TRY(hipMemcpyAsync(d_meta + o_W, hmeta + o_W, meta_bytes - o_W, hipMemcpyHostToDevice, ctx->stream));
+        if (use_segmap) {
+            hipLaunchKernelGGL(seg_count_kernel, dim3((uint32_t)((cnt + 3) / 4)), dim3(256), 0, ctx->stream, m->d_segmap, d_sw, cnt, d_s,
+                               (uint32_t *)nullptr);
+            PW_TRY(hipGetLastError());
         }
         SimBatch b{};
         b.gram = d_g; b.stride = (uint64_t)ld * ld; b.ld = ld; b.n = n; b.W = d_W; b.kind = params->identity_kind;

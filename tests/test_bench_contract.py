@@ -48,7 +48,7 @@ def test_bench_single_gpu_line():
     assert ap["windows"] == 96 and ap["windows_per_s"] > 0 and ap["roofline"]["bound"] == "mfma" and ap["roofline"]["unit"] == "TFLOP/s"
     assert abs(ap["roofline"]["frac"] - ap["roofline"]["achieved"] / ap["roofline"]["peak"]) < 1e-12
     # ... and the dominant kernel alone from HIP events on its stream: shorter than the call, hence a higher fraction
-    assert ap["roofline"]["gram_kernel_launches"] == 3 and 0 < ap["roofline"]["gram_kernel_ms_avg"] < ap["s_per_call"] * 1e3
+    assert ap["roofline"]["gram_kernel_launches"] == 5 and 0 < ap["roofline"]["gram_kernel_ms_avg"] < ap["s_per_call"] * 1e3
     assert ap["roofline"]["gram_kernel_frac"] > ap["roofline"]["frac"]
 
 

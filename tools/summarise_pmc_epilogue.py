@@ -6,12 +6,12 @@ import csv
 import glob
 import sys
 
-KERNELS = ("pica2_kernel", "hfst_kernel", "gram_fp4_kernel")
+KERNELS = ("pica2_small_kernel", "hfst_small_kernel", "pica2_kernel", "hfst_kernel", "gram_fp4_kernel")
 rows = collections.defaultdict(lambda: collections.defaultdict(dict))  # kernel -> launch ordinal -> counter -> value
 for f in sorted(glob.glob(sys.argv[1] + "/g*/**/p_counter_collection.csv", recursive=True)):
     seen = collections.defaultdict(dict)
     for r in csv.DictReader(open(f)):
-        k = next((k for k in KERNELS if k + "(" in r["Kernel_Name"]), None)
+        k = next((k for k in KERNELS if k + "(" in r["Kernel_Name"] or k + "<" in r["Kernel_Name"]), None)
         if not k:
             continue
         d = seen[k].setdefault(r["Dispatch_Id"], len(seen[k]))

@@ -1610,6 +1610,7 @@ IMPOP_API int impop_pairwise_scan(impop_ctx *ctx, const impop_matrix *m, const i
         SimBatch b{};
         b.gram = d_g; b.stride = (uint64_t)ld * ld; b.ld = ld; b.n = n; b.W = d_W; b.kind = params->identity_kind;
         b.g16 = g16 ? 1u : 0u;
+        b.max_W = call_max_W;
         b.round_digits = params->round_digits < 0 ? -1 : params->round_digits;
         b.seg_first = one_to_one ? nullptr : d_first; b.seg_count = one_to_one ? nullptr : d_count;
         if (compact_weighted(m)) {  // the dropped all-ones sites' summed weights, from the host prefix sums

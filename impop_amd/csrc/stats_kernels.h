@@ -27,6 +27,7 @@ struct SimBatch {
     const uint32_t *add;
     uint32_t *err;  // optional device error word (internal.h DEV_ERR_*): set by the launch_* functions
     uint32_t g16;   // gram mode: the counts are uint16 (pairwise.hip writes them so when every window's W < 65536: half the bytes)
+    uint64_t max_W; // gram mode, optional: no problem's W exceeds this (0 = not stated); lets a launch pick 32-bit Hamming arithmetic
 };
 
 struct SimView {

@@ -1,8 +1,8 @@
 // stats_small.hip — pica2 (pica2.py:60-169) and h-fst (h-fst.py:130-249) on the WINDOW-STATISTICS shape of the all-pairs
-// path: Gram problems of up to 512 sequences, `match` identity, uint16 counts, one Gram matrix per problem — what
+// path: Gram problems of up to 512 sequences, `match` identity, counts of 16 or 32 bits (W < 2^30), one Gram matrix per problem or a sum of segments — what
 // impop_pairwise_scan hands over for disjoint windows of a few hundred haplotypes (BASELINE configs 1-4).  Same decisions and
 // the same identities as the general kernels of stats.hip (which keep every other shape: dense .sim problems, `dice`, handed-in
-// seed orders, segment sums of sliding windows, int32 counts, thousands of sequences); what differs is the data layout.
+// seed orders, windows as heavy as 2^30, thousands of sequences); what differs is the data layout.
 //
 // The general kernels walk a row four positions per lane (16-byte loads) and keep sets of positions in an interleaved bit
 // layout; their per-pair work is tens of instructions and every load sits behind its own wait.  Counters over 4096 windows x
@@ -55,8 +55,8 @@ __device__ __forceinline__ double ident_of(const SimView &S, const double *tbl, 
 //  one matrix per problem (SEG false): all loads of the batch go out before the first is consumed;
 //  a problem that is the SUM of nseg consecutive matrices (sliding windows sharing elementary segments, stats_kernels.h SimBatch):
 //  row by row, two segments' loads in flight, added up once both have been issued (nseg == 0: the counts are 0).
-template <uint32_t NWK, int U, bool SEG, class OFF>
-__device__ __forceinline__ void row_counts(const uint16_t *__restrict__ g, uint32_t nseg, uint32_t sstride, const bool (&lv)[U],
+template <uint32_t NWK, int U, bool SEG, typename CT, class OFF>
+__device__ __forceinline__ void row_counts(const CT *__restrict__ g, uint32_t nseg, uint32_t sstride, const bool (&lv)[U],
                                            const uint32_t (&k0)[U], uint32_t nw, int32_t junk, OFF off, int32_t (&I)[U][NWK]) {
     if (!SEG) {
 #pragma unroll
@@ -94,8 +94,8 @@ __device__ __forceinline__ void row_counts(const uint16_t *__restrict__ g, uint3
     }
 }
 // one entry of the problem (all segments)
-template <bool SEG>
-__device__ __forceinline__ int32_t one_count(const uint16_t *__restrict__ g, uint32_t nseg, uint32_t sstride, uint32_t off) {
+template <bool SEG, typename CT>
+__device__ __forceinline__ int32_t one_count(const CT *__restrict__ g, uint32_t nseg, uint32_t sstride, uint32_t off) {
     if (!SEG) return (int32_t)g[off];
     int32_t v = 0;
     for (uint32_t s = 0; s < nseg; ++s) v += (int32_t)g[s * sstride + off];
@@ -131,8 +131,8 @@ __device__ __forceinline__ int32_t match_cutoff_wave(const SimView &S, double th
 // visited once as (list index q, list index p > q): q < na, p < na is a pair inside A, q < na <= p a pair between, na <= q a
 // pair inside B.  Lane L owns list indices L, L + 64, ...; a wave takes rows q and the words of the list right of them.
 // NWK words of the list (4: up to 256 members, 8: up to 512), U rows in flight — U * NWK = 16 loads either way.
-template <uint32_t NWK, int U, bool SEG>
-__device__ __forceinline__ void hfst_small_rows(const SimView &S, const double *tbl, const uint16_t *__restrict__ g, uint32_t ld, uint32_t wave,
+template <uint32_t NWK, int U, bool SEG, typename CT>
+__device__ __forceinline__ void hfst_small_rows(const SimView &S, const double *tbl, const CT *__restrict__ g, uint32_t ld, uint32_t wave,
                                                 uint32_t lane, uint32_t na, uint32_t nmem, uint32_t nw, const uint16_t *mpos,
                                                 const int32_t *dg_l, double &accA, double &accB, double &accX) {
     const int32_t junk = (int32_t)lane;  // see skipped_load
@@ -180,7 +180,7 @@ __device__ __forceinline__ void hfst_small_rows(const SimView &S, const double *
             }
         }
         // the pair's entry in the upper triangle (the part the Gram kernel writes)
-        row_counts<NWK, U, SEG>(g, S.nseg, (uint32_t)S.seg_stride, lv, k0, nw, junk,
+        row_counts<NWK, U, SEG, CT>(g, S.nseg, (uint32_t)S.seg_stride, lv, k0, nw, junk,
                                 [&](int u, uint32_t k) { return (pr[u] < pos[k] ? pr[u] : pos[k]) * ld + (pr[u] < pos[k] ? pos[k] : pr[u]); }, I);
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -202,7 +202,7 @@ __device__ __forceinline__ void hfst_small_rows(const SimView &S, const double *
     }
 }
 
-template <bool SEG>
+template <bool SEG, typename CT>
 __global__ __launch_bounds__(SM_T, SEG ? 4 : 5) void hfst_small_kernel(SimBatch batch, const uint8_t *__restrict__ in_a,
                                                              const uint8_t *__restrict__ in_b, const uint64_t *__restrict__ seq_len,
                                                              HfstOut *__restrict__ out) {
@@ -214,10 +214,10 @@ __global__ __launch_bounds__(SM_T, SEG ? 4 : 5) void hfst_small_kernel(SimBatch 
     __shared__ double shd[SM_T / 64];
     const uint64_t prob = blockIdx.x;
     SimView S = sim_view(batch, prob);
-    S.dense = nullptr; S.g16 = 1;
+    S.dense = nullptr; S.g16 = sizeof(CT) == 2 ? 1u : 0u;  // (sim_view took the problem's base from batch.g16: the launch matches CT to it)
     if (!SEG) S.nseg = 1;
     const uint32_t n = batch.n, tid = threadIdx.x, lane = tid & 63, wave = uni(tid >> 6), ld = S.ld;
-    const uint16_t *__restrict__ g = reinterpret_cast<const uint16_t *>(S.gram);
+    const CT *__restrict__ g = reinterpret_cast<const CT *>(S.gram);
     for (uint32_t i = tid; i < SM_N; i += SM_T) {  // (one round of loads for the workgroup; read one by one by the listing wave
         uint32_t cc = 0;                           //  they were sixteen dependent round trips at the head of every problem)
         if (i < n) {
@@ -245,11 +245,11 @@ __global__ __launch_bounds__(SM_T, SEG ? 4 : 5) void hfst_small_kernel(SimBatch 
     }
     __syncthreads();
     const uint32_t na = uni(sh_na), nb = uni(sh_nb), nmem = na + nb, nw = (nmem + 63) >> 6;
-    for (uint32_t p = tid; p < nmem; p += SM_T) dg_l[p] = one_count<SEG>(g, S.nseg, (uint32_t)S.seg_stride, (uint32_t)mpos[p] * (ld + 1));
+    for (uint32_t p = tid; p < nmem; p += SM_T) dg_l[p] = one_count<SEG, CT>(g, S.nseg, (uint32_t)S.seg_stride, (uint32_t)mpos[p] * (ld + 1));
     __syncthreads();
     double accA = 0.0, accB = 0.0, accX = 0.0;
-    if (nw <= 4) hfst_small_rows<4, 4, SEG>(S, tbl, g, ld, wave, lane, na, nmem, nw, mpos, dg_l, accA, accB, accX);
-    else hfst_small_rows<8, 2, SEG>(S, tbl, g, ld, wave, lane, na, nmem, nw, mpos, dg_l, accA, accB, accX);
+    if (nw <= 4) hfst_small_rows<4, 4, SEG, CT>(S, tbl, g, ld, wave, lane, na, nmem, nw, mpos, dg_l, accA, accB, accX);
+    else hfst_small_rows<8, 2, SEG, CT>(S, tbl, g, ld, wave, lane, na, nmem, nw, mpos, dg_l, accA, accB, accX);
     accA = block_sum(accA, shd); accB = block_sum(accB, shd); accX = block_sum(accX, shd);
     if (tid == 0) {
         const uint64_t a_ = na, b_ = nb;  // every pair is present on a Gram problem: the counts are the class sizes' products
@@ -269,7 +269,7 @@ __global__ __launch_bounds__(SM_T, SEG ? 4 : 5) void hfst_small_kernel(SimBatch 
 //  (row AND free), the candidates it absorbed drop out, and so on.
 //  Step 2-3: up to 64 groups a thread per representative pair; beyond, a wave per representative row against a
 //  per-position frequency (0 where the position represents nothing), identities from the Hamming-distance memo.
-template <bool SEG>
+template <bool SEG, typename CT>
 __global__ __launch_bounds__(SM_T, SEG ? 4 : 5) void pica2_small_kernel(SimBatch batch, const uint32_t *__restrict__ idx, uint32_t m, double thr,
                                                               const uint64_t *__restrict__ seq_len, Pica2Out *__restrict__ out) {
     __shared__ double tbl[SIM_TBL_N];
@@ -282,17 +282,17 @@ __global__ __launch_bounds__(SM_T, SEG ? 4 : 5) void pica2_small_kernel(SimBatch
     __shared__ double shd[SM_T / 64];
     const uint64_t prob = blockIdx.x;
     SimView S = sim_view(batch, prob);
-    S.dense = nullptr; S.g16 = 1;
+    S.dense = nullptr; S.g16 = sizeof(CT) == 2 ? 1u : 0u;  // (sim_view took the problem's base from batch.g16: the launch matches CT to it)
     if (!SEG) S.nseg = 1;
     const uint32_t nseg = S.nseg, sstride = (uint32_t)S.seg_stride;
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = uni(tid >> 6), ld = S.ld;
-    const uint16_t *__restrict__ g = reinterpret_cast<const uint16_t *>(S.gram);
+    const CT *__restrict__ g = reinterpret_cast<const CT *>(S.gram);
     const int32_t junk = (int32_t)lane;  // see skipped_load
     const uint32_t nw = (m + 63) >> 6;
     for (uint32_t o = tid; o < SM_N; o += SM_T) {
         const uint32_t e = o < m ? (idx ? idx[o] : o) : 0u;
         epos[o] = (uint16_t)e;
-        dg_l[o] = o < m ? one_count<SEG>(g, nseg, sstride, e * (ld + 1)) : 0;
+        dg_l[o] = o < m ? one_count<SEG, CT>(g, nseg, sstride, e * (ld + 1)) : 0;
     }
     if (wave == 0) {
         const int32_t hc = match_cutoff_wave(S, thr);
@@ -372,7 +372,7 @@ __global__ __launch_bounds__(SM_T, SEG ? 4 : 5) void pica2_small_kernel(SimBatch
                 row[u] = (uint32_t)__builtin_amdgcn_readlane((int)rowst, (int)j);
             }
             // positions ascend, so do the elements: (row, column) is in the upper triangle
-            row_counts<SM_W, 2, SEG>(g, nseg, sstride, lv, k0, nw, junk, [&](int u, uint32_t k) { return row[u] + ek[k]; }, I);
+            row_counts<SM_W, 2, SEG, CT>(g, nseg, sstride, lv, k0, nw, junk, [&](int u, uint32_t k) { return row[u] + ek[k]; }, I);
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 const uint32_t b = b0 + (SM_T / 64) * u;
@@ -481,7 +481,7 @@ __global__ __launch_bounds__(SM_T, SEG ? 4 : 5) void pica2_small_kernel(SimBatch
                 row[u] = (uint32_t)__builtin_amdgcn_readlane((int)(t ? rows_[1] : rows_[0]), (int)j);
                 k0[u] = rr[u] >> 6;
             }
-            row_counts<SM_W, 2, SEG>(g, nseg, sstride, lv, k0, nw, junk, [&](int u, uint32_t k) { return row[u] + ek[k]; }, I);
+            row_counts<SM_W, 2, SEG, CT>(g, nseg, sstride, lv, k0, nw, junk, [&](int u, uint32_t k) { return row[u] + ek[k]; }, I);
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 if (!lv[u]) continue;
@@ -507,7 +507,7 @@ __global__ __launch_bounds__(SM_T, SEG ? 4 : 5) void pica2_small_kernel(SimBatch
             const uint32_t a = t / G, b = t - a * G;
             if (a >= b) continue;
             const uint32_t ra = rep[a], rb = rep[b];  // ra < rb: the groups are numbered by their seeds, which ascend
-            const int32_t H = dg_l[ra] + dg_l[rb] - 2 * one_count<SEG>(g, nseg, sstride, (uint32_t)epos[ra] * ld + epos[rb]);
+            const int32_t H = dg_l[ra] + dg_l[rb] - 2 * one_count<SEG, CT>(g, nseg, sstride, (uint32_t)epos[ra] * ld + epos[rb]);
             const double s = match_identity(S.W, (int64_t)H, S.round_digits);
             acc += ((1 - s) * ((double)gsz[a] / total)) * ((double)gsz[b] / total);
         }
@@ -529,7 +529,9 @@ __global__ __launch_bounds__(SM_T, SEG ? 4 : 5) void pica2_small_kernel(SimBatch
 
 bool small_shape(const SimBatch &b) {
     static const bool off = [] { const char *e = getenv("IMPOP_EPILOGUE_SMALL"); return e && e[0] == '0'; }();  // A/B and test switch
-    return !off && b.gram && !b.dense && b.g16 && (b.seg_first != nullptr) == (b.seg_count != nullptr) && b.kind == IMPOP_IDENTITY_MATCH &&
+    // counts of 16 or 32 bits; Hamming distances are formed in 32-bit arithmetic: W < 2^30 (uint16 counts imply W < 2^16)
+    const bool w_ok = b.g16 || (b.max_W != 0 && b.max_W < (1ull << 30));
+    return !off && b.gram && !b.dense && w_ok && (b.seg_first != nullptr) == (b.seg_count != nullptr) && b.kind == IMPOP_IDENTITY_MATCH &&
            b.ld <= 4096;  // (element offsets are 32-bit: a problem's segments, at most a few thousand matrices of ld x ld, stay below 2^32)
 }
 
@@ -544,22 +546,23 @@ int launch_pica2_small(impop_ctx *ctx, const SimBatch &b, uint64_t n_problems, c
                        const uint64_t *d_seq_len, Pica2Out *d_out) {
     SimBatch be = b;
     be.err = ctx->d_err;
-    if (b.seg_first)
-        hipLaunchKernelGGL(pica2_small_kernel<true>, dim3((uint32_t)n_problems), dim3(SM_T), 0, ctx->stream, be, d_idx, n_el, threshold,
-                           d_seq_len, d_out);
-    else
-        hipLaunchKernelGGL(pica2_small_kernel<false>, dim3((uint32_t)n_problems), dim3(SM_T), 0, ctx->stream, be, d_idx, n_el, threshold,
-                           d_seq_len, d_out);
+#define LAUNCH_P2(SEG, CT)                                                                                                      \
+    hipLaunchKernelGGL((pica2_small_kernel<SEG, CT>), dim3((uint32_t)n_problems), dim3(SM_T), 0, ctx->stream, be, d_idx, n_el, threshold, \
+                       d_seq_len, d_out)
+    if (b.seg_first) { if (b.g16) LAUNCH_P2(true, uint16_t); else LAUNCH_P2(true, int32_t); }
+    else { if (b.g16) LAUNCH_P2(false, uint16_t); else LAUNCH_P2(false, int32_t); }
+#undef LAUNCH_P2
     HIP_TRY(hipGetLastError());
     return IMPOP_OK;
 }
 
 int launch_hfst_small(impop_ctx *ctx, const SimBatch &b, uint64_t n_problems, const uint8_t *d_in_a, const uint8_t *d_in_b,
                       const uint64_t *d_seq_len, HfstOut *d_out) {
-    if (b.seg_first)
-        hipLaunchKernelGGL(hfst_small_kernel<true>, dim3((uint32_t)n_problems), dim3(SM_T), 0, ctx->stream, b, d_in_a, d_in_b, d_seq_len, d_out);
-    else
-        hipLaunchKernelGGL(hfst_small_kernel<false>, dim3((uint32_t)n_problems), dim3(SM_T), 0, ctx->stream, b, d_in_a, d_in_b, d_seq_len, d_out);
+#define LAUNCH_HF(SEG, CT) \
+    hipLaunchKernelGGL((hfst_small_kernel<SEG, CT>), dim3((uint32_t)n_problems), dim3(SM_T), 0, ctx->stream, b, d_in_a, d_in_b, d_seq_len, d_out)
+    if (b.seg_first) { if (b.g16) LAUNCH_HF(true, uint16_t); else LAUNCH_HF(true, int32_t); }
+    else { if (b.g16) LAUNCH_HF(false, uint16_t); else LAUNCH_HF(false, int32_t); }
+#undef LAUNCH_HF
     HIP_TRY(hipGetLastError());
     return IMPOP_OK;
 }

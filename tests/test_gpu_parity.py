@@ -769,17 +769,17 @@ np.save(sys.argv[1], np.concatenate(recs))
 print(h.hexdigest())
 """
     # ... and the same for the other storage / scheduling choices of the all-pairs path that a caller must never see: chains of
-    # windows per Gram ticket vs one window per ticket; counts as uint16 where they fit vs always int32.  The window-statistics
-    # kernels (stats_small.hip) take uint16 counts only: int32 counts go through the general epilogue kernels, whose sums run in
-    # another order — byte-identical to the default build with IMPOP_EPILOGUE_SMALL=0 (and to the general kernels without their
-    # compile-time variants, IMPOP_EPILOGUE_FAST=0), equal to the window-statistics kernels' records within the tolerance policy.
+    # windows per Gram ticket vs one window per ticket; counts as uint16 where they fit vs always int32.  And the two families of
+    # epilogue kernels: the window-statistics kernels (stats_small.hip, the default here) and the general ones
+    # (IMPOP_EPILOGUE_SMALL=0; with int32 counts; without their compile-time variants, IMPOP_EPILOGUE_FAST=0) — byte-identical
+    # inside a family, equal across the two within the tolerance policy (their sums run in another order).
     import tempfile
     from conftest import stat_close
     outs, recs = {}, {}
     with tempfile.TemporaryDirectory() as td:
         for tag, extra in (("default", {}), ("no polarity", {"IMPOP_NO_POLARITY": "1"}), ("no chains", {"IMPOP_GRAM_CHAIN": "1"}),
-                           ("long chains", {"IMPOP_GRAM_CHAIN": "8"}),
-                           ("general", {"IMPOP_EPILOGUE_SMALL": "0"}), ("general, int32 counts", {"IMPOP_GRAM_U16": "0"}),
+                           ("long chains", {"IMPOP_GRAM_CHAIN": "8"}), ("int32 counts", {"IMPOP_GRAM_U16": "0"}),
+                           ("general", {"IMPOP_EPILOGUE_SMALL": "0"}), ("general, int32 counts", {"IMPOP_EPILOGUE_SMALL": "0", "IMPOP_GRAM_U16": "0"}),
                            ("general, runtime variants", {"IMPOP_EPILOGUE_SMALL": "0", "IMPOP_EPILOGUE_FAST": "0"})):
             env = dict(os.environ, PYTHONPATH=ROOT, **extra)
             path = os.path.join(td, tag.replace(" ", "_").replace(",", "") + ".npy")
@@ -787,7 +787,7 @@ print(h.hexdigest())
             assert r.returncode == 0, (tag, r.stderr[-2000:])
             outs[tag] = r.stdout.strip()
             recs[tag] = np.load(path)
-    small = {outs[t] for t in ("default", "no polarity", "no chains", "long chains")}
+    small = {outs[t] for t in ("default", "no polarity", "no chains", "long chains", "int32 counts")}
     general = {outs[t] for t in outs if t.startswith("general")}
     assert len(outs["default"]) == 64 and len(small) == 1 and len(general) == 1, outs
     a, b = recs["default"], recs["general"]

@@ -1438,7 +1438,7 @@ IMPOP_API int impop_pairwise_scan(impop_ctx *ctx, const impop_matrix *m, const i
             }
         }
     }
-    // Chunks of consecutive (in `ord`) windows whose cells fit the Gram scratch (<= ~4 GiB of 288): large
+    // Chunks of consecutive (in `ord`) windows whose cells fit the Gram scratch (<= ~8 GiB of 288): large
     // chunks keep the persistent Gram grid's last, partially filled round of tasks small next to the launch
     // weighted matrices need a second Gram buffer (the plane partials) only where the planes are NOT walked inside the
     // Gram task: the int8 kernel, or a window as heavy as 2^24 (launch_gram_any)
@@ -1450,8 +1450,8 @@ IMPOP_API int impop_pairwise_scan(impop_ctx *ctx, const impop_matrix *m, const i
     }
     lap("cells");
     const size_t gram_bytes = (size_t)ld * ld * 4;
-    uint64_t cap = ((plane_buffer ? 2ull : 4ull) << 30) / gram_bytes;
-    if (cap > 4096) cap = 4096;
+    uint64_t cap = ((plane_buffer ? 4ull : 8ull) << 30) / gram_bytes;  // (a chromosome of 50 kb windows — 4854 on chr2 — is one chunk)
+    if (cap > 8192) cap = 8192;
     cap = std::min<uint64_t>(cap, std::max<uint64_t>(cells.size(), n_windows));  // a short call stages (and copies) short tables
     if (cap < 1) cap = 1;
     void *d = nullptr;

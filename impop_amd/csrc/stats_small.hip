@@ -75,15 +75,16 @@ __device__ __forceinline__ void row_counts(const CT *__restrict__ g, uint32_t ns
             if (!lv[u]) continue;
             for (uint32_t s0 = 0; s0 < nseg; s0 += 2) {
                 const bool two = s0 + 1 < nseg;
-                const uint32_t b0 = s0 * sstride, b1 = (two ? s0 + 1 : s0) * sstride;
+                // (a segment's base in 64 bits, uniform: ld^2 elements per matrix times hundreds of segments passes 2^32)
+                const CT *__restrict__ g0 = g + (uint64_t)s0 * sstride, *__restrict__ g1 = g + (uint64_t)(two ? s0 + 1 : s0) * sstride;
                 int32_t T0[NWK], T1[NWK];
 #pragma unroll
                 for (uint32_t k = 0; k < NWK; ++k) {
                     T0[k] = junk; T1[k] = junk;
                     if (k >= k0[u] && k < nw) {
                         const uint32_t o = off(u, k);
-                        T0[k] = (int32_t)g[b0 + o];
-                        if (two) T1[k] = (int32_t)g[b1 + o];
+                        T0[k] = (int32_t)g0[o];
+                        if (two) T1[k] = (int32_t)g1[o];
                     }
                 }
 #pragma unroll
@@ -98,7 +99,7 @@ template <bool SEG, typename CT>
 __device__ __forceinline__ int32_t one_count(const CT *__restrict__ g, uint32_t nseg, uint32_t sstride, uint32_t off) {
     if (!SEG) return (int32_t)g[off];
     int32_t v = 0;
-    for (uint32_t s = 0; s < nseg; ++s) v += (int32_t)g[s * sstride + off];
+    for (uint32_t s = 0; s < nseg; ++s) v += (int32_t)(g + (uint64_t)s * sstride)[off];
     return v;
 }
 
@@ -532,7 +533,7 @@ bool small_shape(const SimBatch &b) {
     // counts of 16 or 32 bits; Hamming distances are formed in 32-bit arithmetic: W < 2^30 (uint16 counts imply W < 2^16)
     const bool w_ok = b.g16 || (b.max_W != 0 && b.max_W < (1ull << 30));
     return !off && b.gram && !b.dense && w_ok && (b.seg_first != nullptr) == (b.seg_count != nullptr) && b.kind == IMPOP_IDENTITY_MATCH &&
-           b.ld <= 4096;  // (element offsets are 32-bit: a problem's segments, at most a few thousand matrices of ld x ld, stay below 2^32)
+           b.ld <= 4096;  // (element offsets inside a matrix are 32-bit, elements and positions 16-bit)
 }
 
 }  // namespace

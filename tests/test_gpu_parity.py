@@ -1757,3 +1757,32 @@ def test_window_statistics_kernels_edge_shapes(ctx, oracle):
             for k, v in h.items():
                 assert stat_close(k, float(r[k]), v, h["dxy"]), what + (k, float(r[k]), v)
         bm.free()
+
+
+def test_pairwise_scan_in_several_chunks(ctx, oracle):
+    """A call with more windows than Gram matrices fit one chunk of the scratch (8192): the records must not depend on where the
+    chunks were cut — equal, byte for byte, to the same windows asked for in two halves — for disjoint windows and for sliding
+    ones (shared segment matrices; a window's segments must not straddle a cut); a few windows against the oracle."""
+    rng = np.random.default_rng(77)
+    n, wl, nwin = 40, 24, 9000
+    for step in (wl, wl // 3):
+        W = (nwin - 1) * step + wl
+        f = (rng.random((6, W)) < 0.5).astype(np.uint8)
+        m = f[rng.integers(0, 6, size=n)] ^ (rng.random((n, W)) < 0.01).astype(np.uint8)
+        bm = ctx.upload_dense(m, keep_hap_major=True)
+        inA = (np.arange(n) < 15).astype(np.uint8); inB = (np.arange(n) >= 20).astype(np.uint8)
+        wins = [(k * step, k * step + wl, wl) for k in range(nwin)]
+        kw = dict(kind="match", threshold=0.9, round_digits=3, s_scope=2)
+        whole = bm.pairwise_scan(wins, None, inA, inB, **kw)
+        halves = np.concatenate([bm.pairwise_scan(wins[:4321], None, inA, inB, **kw), bm.pairwise_scan(wins[4321:], None, inA, inB, **kw)])
+        assert whole.tobytes() == halves.tobytes(), step
+        bits = oracle.pack_hap_major(m)
+        for k in (0, 4095, 4096, 4499, 4500, 8191, 8192, nwin - 1):
+            a, b, L = wins[k]
+            sim = oracle.identity(oracle.pairwise_counts(bits, n, a, b), b - a, 0)
+            pi, ps, _, G = oracle.pica2(sim, 0.9, L, 3)
+            assert int(whole[k]["n_groups"]) == G and rel_close(float(whole[k]["pi"]), pi, REL, 0.0), (step, k)
+            h, _ = oracle.hfst(sim, inA, inB, L, 3)
+            for key, v in h.items():
+                assert stat_close(key, float(whole[k][key]), v, h["dxy"]), (step, k, key)
+        bm.free()

@@ -53,7 +53,7 @@ def main():
     in_a = np.arange(n) < 1000
     in_b = np.arange(n) >= 3000
     timed("pairwise_scan_200x50kb", lambda: bm.pairwise_scan(wins200, None, in_a, in_b, kind="match", threshold=0.999, round_digits=5),
-          pair_macs * 50000 * 200, reps=2, note="Gram + pica2 (-t 0.999 -r 5) + h-fst + S + D for 200 windows, chunks of <= 64 Gram matrices")
+          pair_macs * 50000 * 200, reps=2, note="Gram + pica2 (-t 0.999 -r 5) + h-fst + S + D for 200 windows, chunks of <= 128 Gram matrices")
     timed("pairwise_scan_single_window", lambda: bm.pairwise_scan([(0, W, W)], None, in_a, in_b, kind="match", threshold=0.999, round_digits=5),
           pair_macs * W, reps=2, note="one 10^7-site window end to end")
     for label, wins in (("scan_single_window", [(0, W, W)]), ("scan_200x50kb", wins200)):

@@ -259,6 +259,9 @@ struct GramPlanes {          // bit planes of the site weights (weight_planes_ke
     uint32_t bits;           // planes with any set bit
 };
 constexpr uint32_t FP4_MAX_SLICE_PAIRS = (1u << 24) / 128;  // fp32 accumulators stay exact integers
+#ifndef IMPOP_GRAM_ORDER
+#define IMPOP_GRAM_ORDER 0  // order of a window's tile-pair tasks in its queue (A/B builds: 1, 2; measured equal, profiles/r03_gram_experiments.txt §12)
+#endif
 #ifndef IMPOP_GRAM_RING
 #define IMPOP_GRAM_RING 0  // 0: operands straight into three rotating register cell buffers (shipped); 1: prefetched through a
                           // per-wave LDS ring, 2-3 quads ahead (A/B builds: tools/build_variants.py pairwise.hip ring1:-DIMPOP_GRAM_RING=1).
@@ -748,9 +751,24 @@ __global__ __launch_bounds__(256, 2) void gram_fp4_kernel(const uint32_t *__rest
                 wstep = 8;
             } else { const uint64_t i = q + 8ull * k; win = (uint32_t)(i / slots); t2 = (uint32_t)(i % slots); }
             const uint32_t ks = t2 % ksplit;
-            uint32_t rem = t2 / ksplit, ti = 0;
+            uint32_t rem = t2 / ksplit, ti = 0, tj;
+#if IMPOP_GRAM_ORDER == 1  // A/B build (tools/build_variants.py): a window's off-diagonal tile pairs first, its diagonal ones last
+            const uint32_t n_off = n_tiles * (n_tiles - 1) / 2;
+            if (rem < n_off) {
+                while (rem >= n_tiles - 1 - ti) { rem -= n_tiles - 1 - ti; ++ti; }
+                tj = ti + 1 + rem;
+            } else { ti = tj = rem - n_off; }
+#elif IMPOP_GRAM_ORDER == 2  // ... diagonal ones first
+            if (rem < n_tiles) { ti = tj = rem; }
+            else {
+                rem -= n_tiles;
+                while (rem >= n_tiles - 1 - ti) { rem -= n_tiles - 1 - ti; ++ti; }
+                tj = ti + 1 + rem;
+            }
+#else
             while (rem >= n_tiles - ti) { rem -= n_tiles - ti; ++ti; }
-            const uint32_t tj = ti + rem;
+            tj = ti + rem;
+#endif
             if (ti == tj) gram_task_fp4<true>(rb, nb_row, ti, tj, wins, win, wstep, links, ks, ksplit, out, out_stride, ld, shift, add, wp, ring, out16 != 0);
             else gram_task_fp4<false>(rb, nb_row, ti, tj, wins, win, wstep, links, ks, ksplit, out, out_stride, ld, shift, add, wp, ring, out16 != 0);
         }

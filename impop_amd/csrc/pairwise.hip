@@ -259,6 +259,9 @@ struct GramPlanes {          // bit planes of the site weights (weight_planes_ke
     uint32_t bits;           // planes with any set bit
 };
 constexpr uint32_t FP4_MAX_SLICE_PAIRS = (1u << 24) / 128;  // fp32 accumulators stay exact integers
+#ifndef IMPOP_GRAM_PACK16
+#define IMPOP_GRAM_PACK16 1  // uint16 counts stored two to a dword (0: A/B build with one 2-byte store per count)
+#endif
 #ifndef IMPOP_GRAM_ORDER
 #define IMPOP_GRAM_ORDER 0  // order of a window's tile-pair tasks in its queue (A/B builds: 1, 2; measured equal, profiles/r03_gram_experiments.txt §12)
 #endif
@@ -339,12 +342,32 @@ __device__ __forceinline__ void gram_task_fp4(const uint32_t *__restrict__ rb, u
     // is a UNIFORM pointer per (a, b, e) (scalar arithmetic) plus ONE per-lane 32-bit offset: 144 per-lane 64-bit addresses would be
     // hoisted out of the chain loop and spilled
     const uint32_t lane_elem = (ti * GT + 4 * (lane >> 5)) * ld + tj * GT + r32;  // < ld^2 <= 2^32 (ld <= 65535 + padding)
+    // uint16 counts go out two to a dword: registers e and e + 1 (e even) of a block are the rows r and r + 1 of this lane's
+    // column; a lane swaps both with its neighbour column (DPP quad_perm [1,0,3,2]), even lanes then hold (col, col + 1) of row r,
+    // odd lanes (col - 1, col) of row r + 1 — one 4-byte store per lane instead of two 2-byte ones (half the store instructions;
+    // on short windows a quarter of the launch was its stores, profiles/r03_gram_experiments.txt §10, §13)
+    const uint32_t lane_odd = lane & 1u;
+    const uint32_t lane_elem2 = lane_elem + (lane_odd ? ld - 1u : 0u);  // row r + 1, column col - 1 for the odd lanes
     auto store_blocks = [&](int a_from, int a_to) {  // the 32 x 32 blocks of accumulator rows [a_from, a_to) -> int32 counts
 #pragma unroll
         for (int a = 0; a < 3; ++a)
 #pragma unroll
             for (int b = 0; b < 3; ++b) {
                 if (a < a_from || a >= a_to || (DIAG && b < a)) continue;
+                if (out16 && IMPOP_GRAM_PACK16) {
+#pragma unroll
+                    for (int e = 0; e < 16; e += 2) {
+                        const uint64_t eo = (uint64_t)(32 * a + (e & 3) + 8 * (e >> 2)) * ld + 32 * b;  // uniform element offset of (a, b, e)
+                        const int32_t v0 = (int32_t)((uint32_t)(int32_t)acc[a][b][e] << sh);
+                        const int32_t v1 = (int32_t)((uint32_t)(int32_t)acc[a][b][e + 1] << sh);
+                        const int32_t n0 = __builtin_amdgcn_mov_dpp(v0, 0xB1, 0xF, 0xF, true);  // the neighbour column's two rows
+                        const int32_t n1 = __builtin_amdgcn_mov_dpp(v1, 0xB1, 0xF, 0xF, true);
+                        const uint32_t packed = lane_odd ? (((uint32_t)n1 & 0xFFFFu) | ((uint32_t)v1 << 16))
+                                                         : (((uint32_t)v0 & 0xFFFFu) | ((uint32_t)n0 << 16));
+                        *reinterpret_cast<uint32_t *>(reinterpret_cast<uint16_t *>(o) + eo + lane_elem2) = packed;
+                    }
+                    continue;
+                }
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
                     const uint64_t eo = (uint64_t)(32 * a + (e & 3) + 8 * (e >> 2)) * ld + 32 * b;  // uniform element offset of (a, b, e)

@@ -33,10 +33,10 @@ def log(*a):
 
 def pmc_traffic(n_hap, window, n_windows):
     """HBM bytes per launch of the streaming kernel from the committed rocprofv3 PMC passes
-    (profiles/r03e_pmc_hbm_traffic.json, written by tools/summarise_pmc_traffic.py: FETCH_SIZE x1024x2 +
+    (profiles/r03f_pmc_hbm_traffic.json, written by tools/summarise_pmc_traffic.py: FETCH_SIZE x1024x2 +
     WRITE_SIZE x1024, collected in their own runs as the microarch guide prescribes).  PMC cannot be read live inside this process;
     the figure is reported only when it was collected on this exact workload, else null."""
-    path = os.path.join(ROOT, "profiles", "r03e_pmc_hbm_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r03f_pmc_hbm_traffic.json")
     try:
         with open(path) as f:
             d = json.load(f)

@@ -160,6 +160,23 @@ def secondary_points(ctx, bm, windows, in_a, in_b, ref_records, extended, n_pair
             cmp_.free()
         except Exception as e:
             out["all_pairs_mode_variable_sites_only"] = {"error": repr(e)}
+        try:  # BASELINE configs[3]'s window shape (10 kb windows at a 5 kb step) at the reference's default chain: overlapping windows
+            # share 5 kb segment Gram matrices, a window's statistics sum two of them
+            import impop_amd
+            kw = dict(kind="match", threshold=0.999, round_digits=5)
+            n_sl = min(len(pw), 4096)
+            sw = impop_amd.fixed_windows(10000 * (n_sl // 2 + 1), 10000, 5000)[:n_sl]
+            pm.pairwise_scan(sw, None, in_a, in_b, **kw)
+            ctx.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(3):
+                got_sl = pm.pairwise_scan(sw, None, in_a, in_b, **kw)
+            dts = (time.perf_counter() - t0) / 3
+            one = pm.pairwise_scan(sw[7:8], None, in_a, in_b, **kw)  # the same window asked for alone: no shared segments
+            out["all_pairs_mode_sliding_10kb_5kb"] = {"windows_per_s": len(sw) / dts, "windows": len(sw), "ms_per_call": dts * 1e3,
+                                                      "window_alone_identical": bool(one.tobytes() == got_sl[7:8].tobytes())}
+        except Exception as e:
+            out["all_pairs_mode_sliding_10kb_5kb"] = {"error": repr(e)}
     if pm is not None:
         pm.free()
     if extended:
